@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ from the UNMODIFIED reference.
+
+Run in the build container (where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+The reference (microsoft/XPretrain CLIP-ViP) has no tests or golden vectors of its own
+(SURVEY.md §4), so these fixtures -- outputs of the reference itself on seeded inputs --
+are what pins ``oracle/clipvip_oracle.py`` and, through it, the HIP path.  The GPU box
+has no /root/reference; it only ever reads the committed ``*.pt`` files.
+
+Fixtures (all fp32, CPU, torch.manual_seed'ed):
+  tiny_e2e.pt        tiny CLIP-ViP (2 vision layers/128 wide/2 heads, 2 text layers) through
+                     reference VidCLIP.forward + NCELearnableTempLoss + backward: state dict,
+                     inputs, features, hidden states, loss, every parameter gradient.
+  attn_forward2.pt   CLIPAttention.forward2 alone for several (M,N,L), with input grads.
+  text_attn.pt       CLIPAttention.forward (causal + ragged padding masks), with input grads.
+  temporal_interp.pt CLIPVisionViPEmbeddings for T in {1,8,12,32} (temporal_size 12).
+  loss.pt            NCELearnableTempLoss / NCELearnableTempLoss_vsc_fc for several batch sizes
+                     and logit scales (incl. both clamp limits 0 and ln 200).
+"""
+import math
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from oracle import clipvip_oracle as O  # noqa: E402
+
+TINY = dict(vision_hidden=128, vision_heads=2, vision_layers=2, vision_inter=192, patch=8, image=32,
+            text_hidden=128, text_heads=2, text_layers=2, text_inter=192, vocab=120, max_pos=16, proj=64)
+
+
+def randomize_(model, seed):
+    """Reference init leaves biases 0, LN affine at (1,0) and temporal_embedding 0
+    (CLIP_ViP.py:166,481-522) -- perturb them so every term is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("logit_scale"):
+                continue
+            if n.endswith(".bias") or "temporal_embedding" in n:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+            elif "layer_norm" in n or "layrnorm" in n or "layernorm" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2 and "embedding" not in n:
+                # reference init stds are ~0.01-0.06 at this width; widen so attention is not ~uniform
+                p.mul_(3.0)
+
+
+def tiny_e2e(ref):
+    torch.manual_seed(1234)
+    cfg_dict = O.hf_config_dict(**TINY)
+    args = ref_import.make_args(cfg_dict, add_cls_num=3, temporal_size=3)
+    model = ref.VidCLIP.VidCLIP(args)
+    randomize_(model, 99)
+    model.train()
+    B, T, Lt = 4, 3, 12
+    video, ids, mask = O.synthetic_inputs(B, T, TINY["image"], Lt, vocab=TINY["vocab"], seed=4321)
+    # one row with EOT in the very last slot and one with the earliest legal EOT
+    ids[0, 2:] = TINY["vocab"] - 1; mask[0] = 0; mask[0, :3] = 1
+    ids[1, 1:-1] = torch.randint(1, TINY["vocab"] - 2, (Lt - 2,)); ids[1, -1] = TINY["vocab"] - 1; mask[1] = 1
+    out = model(video, ids, mask)
+    loss_fn = ref.loss.NCELearnableTempLoss(None)
+    loss = loss_fn(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+    loss.backward()
+    # hidden states through the reference vision/text towers
+    with torch.no_grad():
+        vo = model.clipmodel.vision_model(pixel_values=video, output_hidden_states=True, return_dict=True)
+        to = model.clipmodel.text_model(input_ids=ids, attention_mask=mask, output_hidden_states=True,
+                                        return_dict=True)
+    fx = dict(
+        config=cfg_dict, add_cls_num=3, temporal_size=3,
+        state_dict={k: v.detach().clone() for k, v in model.state_dict().items()},
+        video=video, ids=ids, mask=mask,
+        vis_features=out["vis_features"].detach(), text_features=out["text_features"].detach(),
+        loss=loss.detach(),
+        grads={n: p.grad.detach().clone() for n, p in model.named_parameters()},
+        vision_hidden=[h.detach() for h in vo.hidden_states], vision_last=vo.last_hidden_state.detach(),
+        vision_pooled=vo.pooler_output.detach(),
+        text_hidden=[h.detach() for h in to.hidden_states], text_last=to.last_hidden_state.detach(),
+        text_pooled=to.pooler_output.detach(),
+    )
+    torch.save(fx, os.path.join(HERE, "tiny_e2e.pt"))
+    print("tiny_e2e: loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
+
+
+def _attn_module(ref, D, H, seed):
+    from transformers.models.clip.configuration_clip import CLIPVisionConfig
+    torch.manual_seed(seed)
+    cfg = CLIPVisionConfig(hidden_size=D, num_attention_heads=H, intermediate_size=2 * D, num_hidden_layers=1)
+    m = ref.CLIP_ViP.CLIPAttention(cfg)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * (0.5 / math.sqrt(D) if p.dim() == 2 else 0.1))
+        m.q_proj.weight.mul_(4.0)   # sharpen the softmax
+    return m
+
+
+def attn_forward2(ref):
+    cases = []
+    for (M, N, L), D, H, B in [((4, 2, 49), 128, 2, 2), ((4, 2, 196), 64, 1, 1), ((1, 3, 5), 64, 1, 2),
+                               ((4, 3, 70), 128, 2, 1), ((2, 5, 16), 192, 3, 2)]:
+        m = _attn_module(ref, D, H, 7 + M + N + L)
+        S = M + N * L
+        x = torch.randn(B, S, D, requires_grad=True)
+        y = m.forward2(x, (M, N, L))
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        cases.append(dict(size=(M, N, L), D=D, H=H, x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+                          sd={k: v.detach().clone() for k, v in m.state_dict().items()}))
+    torch.save(cases, os.path.join(HERE, "attn_forward2.pt"))
+    print("attn_forward2:", [c["size"] for c in cases])
+
+
+def text_attn(ref):
+    cases = []
+    enc = ref.CLIP_ViP.CLIPTextTransformer
+    for B, S, D, H, mode in [(3, 12, 128, 2, "ragged"), (2, 32, 64, 1, "ragged"), (2, 7, 64, 1, "none"),
+                             (2, 16, 64, 1, "allpad")]:
+        m = _attn_module(ref, D, H, 31 + S)
+        x = torch.randn(B, S, D, requires_grad=True)
+        causal = enc._build_causal_attention_mask(None, B, S)
+        if mode == "none":
+            mask, am = None, None
+        else:
+            lens = torch.randint(1, S + 1, (B,))
+            lens[0] = S
+            mask = (torch.arange(S)[None] < lens[:, None]).long()
+            if mode == "allpad":
+                mask[1] = 0          # degenerate row: every key padded (finfo.min on all of them)
+            am = ref.CLIP_ViP._expand_mask(mask, x.dtype)
+        y, _ = m(x, None, attention_mask=am, causal_attention_mask=causal)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        cases.append(dict(D=D, H=H, mask=mask, x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+                          sd={k: v.detach().clone() for k, v in m.state_dict().items()}))
+    torch.save(cases, os.path.join(HERE, "text_attn.pt"))
+    print("text_attn:", len(cases))
+
+
+def temporal_interp(ref):
+    from transformers.models.clip.configuration_clip import CLIPVisionConfig
+    torch.manual_seed(5)
+    cfg = CLIPVisionConfig(hidden_size=64, num_attention_heads=1, intermediate_size=128, num_hidden_layers=1,
+                           image_size=16, patch_size=8)
+    add = ref.AttrDict(type="ViP", temporal_size=12, if_use_temporal_embed=1, logit_scale_init_value=4.6,
+                       add_cls_num=3)
+    emb = ref.CLIP_ViP.CLIPVisionViPEmbeddings(cfg, add)
+    with torch.no_grad():
+        emb.temporal_embedding.copy_(torch.randn_like(emb.temporal_embedding))
+        emb.patch_embedding.weight.mul_(0.05)
+    cases = []
+    for T in (1, 8, 12, 32):
+        emb.zero_grad()
+        v = torch.randn(2, T, 3, 16, 16)
+        y, size = emb(v)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        cases.append(dict(T=T, video=v, y=y.detach(), size=tuple(size), gy=gy,
+                          g_temporal=emb.temporal_embedding.grad.clone(),
+                          g_patch=emb.patch_embedding.weight.grad.clone(),
+                          g_pos=emb.position_embedding.weight.grad.clone(),
+                          g_cls=emb.class_embedding.grad.clone(), g_added=emb.added_cls.grad.clone()))
+    torch.save(dict(sd={k: v.detach().clone() for k, v in emb.state_dict().items()}, cases=cases),
+               os.path.join(HERE, "temporal_interp.pt"))
+    print("temporal_interp:", [c["T"] for c in cases])
+
+
+def loss(ref):
+    torch.manual_seed(11)
+    cases = []
+    f1 = ref.loss.NCELearnableTempLoss(None)
+    f2 = ref.loss.NCELearnableTempLoss_vsc_fc(None)
+    for n, d in [(2, 64), (8, 512), (16, 128), (64, 64), (5, 32)]:
+        for ls in (0.0, 4.6, math.log(200.0)):
+            feats = [torch.nn.functional.normalize(torch.randn(n, d), dim=-1).requires_grad_() for _ in range(4)]
+            t = torch.tensor(ls, requires_grad=True)
+            l1 = f1(feats[0], feats[1], t)
+            g1 = torch.autograd.grad(l1, [feats[0], feats[1], t])
+            l2 = f2(feats[0], feats[1], feats[2], feats[3], t)
+            g2 = torch.autograd.grad(l2, feats + [t])
+            cases.append(dict(n=n, d=d, log_scale=ls, feats=[f.detach() for f in feats],
+                              nce=l1.detach(), nce_grads=[g.clone() for g in g1],
+                              vsc_fc=l2.detach(), vsc_fc_grads=[g.clone() for g in g2]))
+    torch.save(cases, os.path.join(HERE, "loss.pt"))
+    print("loss:", len(cases))
+
+
+if __name__ == "__main__":
+    ref = ref_import.load()
+    tiny_e2e(ref)
+    attn_forward2(ref)
+    text_attn(ref)
+    temporal_interp(ref)
+    loss(ref)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".pt"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
