@@ -1,0 +1,175 @@
+/*
+ * xpretrain_hip.h -- C ABI of libxpretrain_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * CLIP-ViP video-text contrastive hot path of microsoft/XPretrain.
+ *
+ * The reference has NO native/FFI layer (pure Python on torch/cuDNN/cuBLAS/apex/Horovod),
+ * so every entry point below cites the reference *Python* call site whose arithmetic it replaces
+ * (paths relative to /root/reference/CLIP-ViP/src).  The Python host side
+ * (xpretrain_amd/modeling/) binds these through ctypes -- see INTEGRATION.md.
+ *
+ * Conventions (SURVEY.md §8b "C-ABI the new extension must export"):
+ *   - plain pointers + sizes; no torch types.  Every pointer is a DEVICE pointer unless named host_*.
+ *   - never allocates, never synchronises, never owns memory; launches only on `stream`
+ *     (a hipStream_t passed as void*); re-entrant (forward thread + autograd thread).
+ *   - returns 0 on success, a negative XP_ERR_* otherwise; xp_last_error() gives the thread-local message.
+ *   - `dtype`: element type of activations / GEMM operands (XP_BF16 or XP_F32).  Parameters that are read
+ *     directly from the fp32 master copy (biases, LayerNorm affine, embedding tables) are always float.
+ *   - sizes are int64_t elements; `ld*` are row strides in elements.
+ */
+#ifndef XPRETRAIN_HIP_H
+#define XPRETRAIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XP_ABI_VERSION 1
+
+enum { XP_BF16 = 0, XP_F32 = 1 };
+enum { XP_OK = 0, XP_ERR_ARG = -1, XP_ERR_LAUNCH = -2, XP_ERR_UNSUPPORTED = -3 };
+
+int xp_abi_version(void);
+const char* xp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ GEMM
+ * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ).  One MFMA kernel family for every dense contraction on
+ * the path: q/k/v/out projections (modeling/CLIP_ViP.py:341-343,379), MLP fc1/fc2 (:393-395), the
+ * patch-embedding conv as a GEMM (:157-159,178), visual/text projections (:1142,1145), and their
+ * autograd backward products (dX = dY.W, dW = dY^T.X).
+ *
+ * Operand storage: a_kstrided/b_kstrided == 0: row index major, k contiguous (A[m*lda + k]);
+ *                  == 1: k major (A[k*lda + m]) -- read through LDS transpose loads, no copy.
+ */
+enum {
+  XP_EPI_NONE = 0,       /* C = acc                                                              */
+  XP_EPI_BIAS = 1,       /* C = acc + bias[n]                                                    */
+  XP_EPI_BIAS_QSCALE = 2,/* C = (acc + bias[n]) * (n < scale_cols ? scale : 1)   q*dh^-0.5 (:341)  */
+  XP_EPI_BIAS_GELU = 3,  /* aux = acc + bias[n];  C = aux * sigmoid(1.702 aux)   quick_gelu (:394) */
+  XP_EPI_BIAS_RESID = 4, /* C = acc + bias[n] + resid[m,n]                       (:455,:460)       */
+  XP_EPI_GELU_BWD = 5,   /* C = acc * d/dx quick_gelu(resid[m,n])                                 */
+  XP_EPI_PATCH = 6,      /* C = acc + tab1[t,n] + tab2[l,n], t=(m%c_grp)/tab_L, l=m%tab_L (:182-185) */
+  XP_EPI_SCALE = 7       /* C = acc * scale                                                      */
+};
+
+typedef struct XpGemmDesc {
+  const void* A; const void* B; void* C;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int32_t a_kstrided, b_kstrided;
+  int32_t in_dtype, out_dtype;          /* XP_BF16 / XP_F32 (out may be F32 with BF16 inputs)     */
+  int32_t epilogue;
+  int32_t split_k;                      /* >1: writes split_k fp32 slabs [split][M][N] to C, EPI_NONE */
+  /* optional row remap  r -> (r / grp) * grp_stride + off + r % grp   (grp == 0: identity)        */
+  int64_t a_grp, a_grp_stride, a_off;   /* applied to A's m index (row, or k-row when a_kstrided)  */
+  int64_t c_grp, c_grp_stride, c_off;   /* applied to the output row (C, aux, resid)               */
+  const float* bias;
+  float scale; int64_t scale_cols;
+  const void* resid; int64_t ldr;       /* dtype = in_dtype                                        */
+  void* aux; int64_t ldaux;             /* dtype = out_dtype                                       */
+  const float* tab1; const float* tab2; int64_t tab_L;
+} XpGemmDesc;
+
+int xp_gemm(const XpGemmDesc* desc, void* stream);
+
+/* out[i] (+)= sum_z slabs[z*n + i], fp32; accumulate != 0 adds into out (gradient accumulation). */
+int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
+
+/* Bias gradient: out[n] (+)= sum_m X[m*ldx + n]; workspace >= xp_colsum_workspace_bytes(). */
+size_t xp_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* out,
+              int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------- LayerNorm
+ * nn.LayerNorm(eps=1e-5) of modeling/CLIP_ViP.py:404-406,855-857,720 (pre_layrnorm, layer_norm1/2,
+ * post_layernorm, final_layer_norm).  Statistics in fp32; mean/rstd saved for the backward.
+ */
+int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                     float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, void* stream);
+size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+/* dx = (dres ? dres : 0) + LN'(dy);  dgamma/dbeta (+)= column sums.  dres may alias dx. */
+int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                     const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                     void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                     int64_t rows, int64_t cols, int32_t dtype,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------- Attention
+ * Fused attention on the packed projection output qkv[B, S, 3, H, 64] (row stride ldqkv elements; q is
+ * already scaled).  head_dim is fixed at 64 (every CLIP ViT-B/L and text tower).
+ *
+ *  mode XP_ATTN_PROXY : CLIPAttention.forward2 (modeling/CLIP_ViP.py:332-381).  S = M + N*L; frame-n
+ *                       queries attend [M proxies | frame n]; proxy queries attend everything.
+ *  mode XP_ATTN_CAUSAL: CLIPAttention.forward text path (:266-330) with the additive -inf causal mask
+ *                       (:788-797) and the finfo.min padding mask (_expand_mask :50-61); pad_mask is
+ *                       int64 [B,S] (1 = keep) or NULL.  M,N,L ignored (pass 0,1,S).
+ *
+ * out[B,S,H*64] (row stride ldo).  stats[B,H,S,2] fp32 = (row max, log row sum) for the backward.
+ */
+enum { XP_ATTN_PROXY = 0, XP_ATTN_CAUSAL = 1 };
+size_t xp_attn_workspace_bytes(int32_t mode, int64_t B, int64_t H, int64_t M, int64_t N, int64_t L);
+int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* stats,
+                const int64_t* pad_mask, int32_t mode, int64_t B, int64_t H, int64_t S,
+                int64_t M, int64_t N, int64_t L, int32_t dtype,
+                void* workspace, size_t workspace_bytes, void* stream);
+/* dqkv[B,S,3,H,64] (same layout as qkv; dq already multiplied by q_scale so it is the gradient of the
+ * un-scaled projection output). */
+int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
+                const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
+                int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------- Embeddings / glue
+ * CLIPVisionViPEmbeddings.forward (modeling/CLIP_ViP.py:168-197).
+ */
+/* frames fp32 [BT,3,H,W] -> patch matrix [BT*gh*gw, 3*P*P] (dtype), k = (c,py,px): the conv-as-GEMM A operand */
+int xp_im2col(const float* video, void* patches, int64_t BT, int64_t H, int64_t W, int64_t P, int32_t dtype, void* stream);
+/* proxy rows: x[b, 0] = class_emb + pos[0]; x[b, 1+i] = added_cls[i] + pos[0]   (:187-191) */
+int xp_vip_proxy_rows(const float* class_emb, const float* added_cls, const float* pos, void* x,
+                      int64_t B, int64_t S, int64_t M, int64_t D, int32_t dtype, void* stream);
+/* gradients of class_embedding, added_cls, position_embedding[1+L], time table [T,D] from dx[B,S,D] */
+size_t xp_vip_embed_bwd_workspace_bytes(int64_t B, int64_t T, int64_t L, int64_t D);
+int xp_vip_embed_bwd(const void* dx, float* d_class, float* d_added, float* d_pos, float* d_time,
+                     int64_t B, int64_t M, int64_t T, int64_t L, int64_t D, int32_t dtype, int32_t accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* CLIPTextEmbeddings.forward (:210-227): x[b,t] = tok[ids[b,t]] + pos[t] */
+int xp_text_embed_fwd(const int64_t* ids, const float* tok, const float* pos, void* x,
+                      int64_t B, int64_t Lt, int64_t D, int64_t vocab, int32_t dtype, void* stream);
+/* d_tok[ids[b,t]] += dx[b,t] (atomic fp32); d_pos[t] (+)= sum_b dx[b,t] */
+int xp_text_embed_bwd(const int64_t* ids, const void* dx, float* d_tok, float* d_pos,
+                      int64_t B, int64_t Lt, int64_t D, int64_t vocab, int32_t dtype, int32_t accumulate, void* stream);
+/* pooled[b] = x[b, idx[b]] (text: idx = ids.argmax(-1), :776 ; vision: idx = 0, :892) and its scatter */
+int xp_argmax_rows(const int64_t* ids, int64_t* idx, int64_t B, int64_t Lt, void* stream);
+int xp_gather_rows(const void* x, const int64_t* idx, void* out, int64_t B, int64_t S, int64_t D, int32_t dtype, void* stream);
+int xp_scatter_rows(const void* dout, const int64_t* idx, void* dx, int64_t B, int64_t S, int64_t D, int32_t dtype, void* stream);
+/* x / ||x||_2 per row (:1148-1149); in `dtype`, out fp32 features; inv_norm saved */
+int xp_l2norm_fwd(const void* x, float* y, float* inv_norm, int64_t rows, int64_t cols, int32_t dtype, void* stream);
+int xp_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* dx, int64_t rows, int64_t cols,
+                  int32_t dtype, void* stream);
+/* fp32 master -> compute dtype copy */
+int xp_cast(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
+int xp_cast_back(const void* src, float* dst, int64_t n, int32_t dtype, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------- Loss
+ * NCELearnableTempLoss.forward (optimization/loss.py:134-141) on gathered unit-norm features
+ * vis[n,d], txt[n,d] (fp32) and the LOG scale parameter: loss = CE(s V T^T, diag) + CE(s T V^T, diag).
+ * One launch computes the loss AND d loss / d{vis, txt, log_scale} (the backward just scales them).
+ */
+size_t xp_nce_loss_workspace_bytes(int64_t n, int64_t d);
+int xp_nce_loss(const float* vis, const float* txt, const float* log_scale, float* loss,
+                float* d_vis, float* d_txt, float* d_log_scale, int64_t n, int64_t d,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* -------------------------------------------------------------------------------------- Diagnostics
+ * Hardware-layout probes used by tests/test_probe_gpu.py to pin the MFMA / LDS-transpose lane maps
+ * this library relies on (out buffers are small device arrays; see csrc/probe.hip). */
+int xp_probe_mfma_bf16(const void* a, const void* b, float* c, void* stream);
+int xp_probe_mfma_f32(const float* a, const float* b, float* c, void* stream);
+int xp_probe_tr16(const void* in /*4096 u16*/, const int32_t* lane_byte_off /*64*/, void* out /*64*4 u16*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+"""GPU: MFMA GEMM family vs torch fp64 matmul on bf16-rounded / fp32 inputs (the kernel's own inputs),
+every operand layout, every epilogue, ragged M/N/K tails, split-K."""
+import pytest
+import torch
+
+from tests.gpu_util import report
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float32]
+# error of the OUTPUT rounding dominates for bf16 (2^-9 relative); accumulation is fp32
+TOL = {torch.bfloat16: 6e-3, torch.float32: 2e-5}
+
+
+def _mk(shape, dtype, scale=1.0):
+    return (torch.randn(shape, device="cuda") * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (204, 132, 200), (8, 512, 768), (1000, 2304, 768)])
+def test_nt_plain(dtype, M, N, K):
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(M + N + K)
+    A, B = _mk((M, K), dtype), _mk((N, K), dtype)
+    C = H.gemm(A, B, M, N, K)
+    ref = A.double() @ B.double().t()
+    assert report(f"gemm_nt {dtype} {M}x{N}x{K}", C, ref, TOL[dtype]) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (204, 768, 2304), (52, 192, 136)])
+def test_nn_b_kstrided(dtype, M, N, K):
+    """dX = dY[M,K] . W[K,N]  (B stored [k][n])"""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(1)
+    A, W = _mk((M, K), dtype), _mk((K, N), dtype)
+    C = H.gemm(A, W, M, N, K, b_kstrided=True)
+    ref = A.double() @ W.double()
+    assert report(f"gemm_nn {dtype} {M}x{N}x{K}", C, ref, TOL[dtype]) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,split", [(128, 128, 256, 1), (768, 3072, 1000, 1), (192, 136, 204, 1), (768, 768, 4000, 8)])
+def test_tn_both_kstrided(dtype, M, N, K, split):
+    """dW[M,N] = dY[K,M]^T . X[K,N]  (both stored [k][row]), optionally split-K over the long contraction."""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(2)
+    Y, X = _mk((K, M), dtype), _mk((K, N), dtype)
+    if split == 1:
+        C = H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, out_dtype=torch.float32)
+    else:
+        slabs = H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, split_k=split)
+        C = H.splitk_reduce(slabs, torch.empty(M, N, device="cuda"))
+    ref = Y.double().t() @ X.double()
+    tol = 2e-5 if dtype == torch.float32 else 1e-5   # fp32 output: only accumulation error
+    assert report(f"gemm_tn {dtype} {M}x{N}x{K} split{split}", C, ref, tol) <= tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_epilogues(dtype):
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(3)
+    M, N, K = 204, 384, 192
+    A, B = _mk((M, K), dtype, 0.5), _mk((N, K), dtype, 0.2)
+    bias = torch.randn(N, device="cuda")
+    R = _mk((M, N), dtype)
+    acc = A.double() @ B.double().t()
+    tol = TOL[dtype]
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)
+    assert report(f"epi_bias {dtype}", C, acc + bias.double(), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=128)
+    ref = acc + bias.double(); ref[:, :128] *= 0.125
+    assert report(f"epi_qscale {dtype}", C, ref, tol) <= tol
+    aux = torch.empty(M, N, dtype=dtype, device="cuda")
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    pre = acc + bias.double()
+    assert report(f"epi_gelu.aux {dtype}", aux, pre, tol) <= tol
+    assert report(f"epi_gelu.act {dtype}", C, pre * torch.sigmoid(1.702 * pre), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R)
+    assert report(f"epi_resid {dtype}", C, acc + bias.double() + R.double(), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_GELU_BWD, resid=R)
+    x = R.double(); s = torch.sigmoid(1.702 * x)
+    assert report(f"epi_gelu_bwd {dtype}", C, acc * (s * (1 + 1.702 * x * (1 - s))), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_SCALE, scale=3.0, out_dtype=torch.float32)
+    assert report(f"epi_scale {dtype}", C, acc * 3.0, 2e-5) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patch_epilogue_and_row_remap(dtype):
+    """conv-as-GEMM epilogue: rows (b,t,l) land in token slot b*S + Mp + t*L + l with + time[t] + pos[l]."""
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(4)
+    Bsz, T, Lp, Mp, D, K = 2, 3, 10, 4, 128, 192
+    S = Mp + T * Lp
+    A, W = _mk((Bsz * T * Lp, K), dtype, 0.3), _mk((D, K), dtype, 0.3)
+    tab_t, tab_l = torch.randn(T, D, device="cuda"), torch.randn(Lp, D, device="cuda")
+    x = torch.zeros(Bsz * S, D, dtype=dtype, device="cuda")
+    H.gemm(A, W, Bsz * T * Lp, D, K, out=x, epilogue=L.EPI_PATCH, tab1=tab_t, tab2=tab_l, tab_L=Lp,
+           c_remap=(T * Lp, S, Mp))
+    ref = (A.double() @ W.double().t()).view(Bsz, T, Lp, D) + tab_t.double()[None, :, None] + tab_l.double()[None, None]
+    full = torch.zeros(Bsz, S, D, dtype=torch.float64, device="cuda")
+    full[:, Mp:] = ref.view(Bsz, T * Lp, D)
+    assert report(f"epi_patch {dtype}", x.view(Bsz, S, D), full, TOL[dtype]) <= TOL[dtype]
+    # dW with the A operand's k-rows remapped the same way (token rows -> patch rows)
+    dx = _mk((Bsz * S, D), dtype)
+    dW = H.gemm(dx, A, D, K, Bsz * T * Lp, a_kstrided=True, b_kstrided=True, lda=D, ldb=K, out_dtype=torch.float32,
+                a_remap=(T * Lp, S, Mp))
+    ref = dx.double().view(Bsz, S, D)[:, Mp:].reshape(-1, D).t() @ A.double()
+    assert report(f"dW_patch_remap {dtype}", dW, ref, 2e-5) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum(dtype):
+    from xpretrain_amd import hip_ops as H
+    X = _mk((1000, 768), dtype)
+    out = H.colsum(X, 1000, 768)
+    assert report(f"colsum {dtype}", out, X.double().sum(0), 1e-5) <= 1e-5
+
+
+def test_bad_arguments_raise():
+    from xpretrain_amd import hip_ops as H
+    A = torch.zeros(8, 12, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="multiples of"):
+        H.gemm(A, A, 8, 8, 12)

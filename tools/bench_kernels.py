@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the individual HIP kernels at BASELINE cfg #2 shapes (B=8, T=12, 224^2, ViT-B/16).
+Run on the GPU box:  python tools/bench_kernels.py [gemm|ln|attn|all]  -> prints one line per kernel."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from xpretrain_amd import hip_ops as H  # noqa: E402
+from xpretrain_amd import _lib as L  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters * 1e3   # us
+
+
+def bench_gemm():
+    M = 8 * 2356
+    bf = torch.bfloat16
+    for name, N, K, kw in [("qkv", 2304, 768, dict(epilogue=L.EPI_BIAS_QSCALE, scale=0.125, scale_cols=768)),
+                           ("out", 768, 768, dict(epilogue=L.EPI_BIAS_RESID)),
+                           ("fc1", 3072, 768, dict(epilogue=L.EPI_BIAS_GELU)),
+                           ("fc2", 768, 3072, dict(epilogue=L.EPI_BIAS_RESID))]:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        bias = torch.zeros(N, device="cuda")
+        out = torch.empty(M, N, dtype=bf, device="cuda")
+        if kw["epilogue"] == L.EPI_BIAS_RESID:
+            kw["resid"] = torch.randn(M, N, device="cuda").to(bf)
+        if kw["epilogue"] == L.EPI_BIAS_GELU:
+            kw["aux"] = torch.empty(M, N, dtype=bf, device="cuda")
+        us = timeit(lambda: H.gemm(A, W, M, N, K, out=out, bias=bias, **kw))
+        print(f"gemm fwd {name:4s} M={M} N={N} K={K}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
+        # dX: dY[M,N] . W[N,K]
+        dY = torch.randn(M, N, device="cuda").to(bf)
+        dX = torch.empty(M, K, dtype=bf, device="cuda")
+        us = timeit(lambda: H.gemm(dY, W, M, K, N, b_kstrided=True, out=dX))
+        print(f"gemm dX  {name:4s}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
+        # dW[N,K] = dY^T X, split-K
+        for split in (4, 8, 16):
+            slabs = torch.empty(split, N, K, device="cuda")
+            dW = torch.empty(N, K, device="cuda")
+            def f():
+                H.gemm(dY, A, N, K, M, a_kstrided=True, b_kstrided=True, lda=N, ldb=K, split_k=split, out=slabs)
+                H.splitk_reduce(slabs, dW)
+            us = timeit(f)
+            print(f"gemm dW  {name:4s} split={split:2d}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
+        us = timeit(lambda: H.colsum(dY, M, N))
+        print(f"colsum   {name:4s}: {us:8.1f} us  {M*N*2/us/1e3:7.1f} GB/s")
+
+
+def bench_ln():
+    M, D = 8 * 2356, 768
+    x = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+    g, b = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
+    us = timeit(lambda: H.layernorm_fwd(x, g, b, M, D))
+    print(f"layernorm fwd {M}x{D}: {us:7.1f} us  {M*D*4/us/1e3:7.1f} GB/s")
+    y, mean, rstd = H.layernorm_fwd(x, g, b, M, D)
+    dy = torch.randn_like(x)
+    us = timeit(lambda: H.layernorm_bwd(dy, x, g, mean, rstd, M, D, dres=dy))
+    print(f"layernorm bwd {M}x{D}: {us:7.1f} us  {M*D*8/us/1e3:7.1f} GB/s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("ln", "all"):
+        bench_ln()

@@ -1,0 +1,97 @@
+"""ctypes binding of libxpretrain_hip.so (the C ABI in include/xpretrain_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C xpretrain_amd/csrc``.
+Loading fails loudly if it is missing -- there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxpretrain_hip.so")
+
+XP_BF16, XP_F32 = 0, 1
+(EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_PATCH, EPI_SCALE) = range(8)
+ATTN_PROXY, ATTN_CAUSAL = 0, 1
+
+i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class XpGemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", i64), ("N", i64), ("K", i64),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("a_kstrided", i32), ("b_kstrided", i32),
+        ("in_dtype", i32), ("out_dtype", i32),
+        ("epilogue", i32), ("split_k", i32),
+        ("a_grp", i64), ("a_grp_stride", i64), ("a_off", i64),
+        ("c_grp", i64), ("c_grp_stride", i64), ("c_off", i64),
+        ("bias", vp),
+        ("scale", f32), ("scale_cols", i64),
+        ("resid", vp), ("ldr", i64),
+        ("aux", vp), ("ldaux", i64),
+        ("tab1", vp), ("tab2", vp), ("tab_L", i64),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/xpretrain_hip.h one-to-one
+SIGNATURES = {
+    "xp_abi_version": (i32, []),
+    "xp_last_error": (C.c_char_p, []),
+    "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
+    "xp_splitk_reduce": (i32, [vp, vp, i64, i32, i32, vp]),
+    "xp_colsum_workspace_bytes": (sz, [i64, i64]),
+    "xp_colsum": (i32, [vp, i64, i64, i64, i32, vp, i32, vp, sz, vp]),
+    "xp_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, i32, vp]),
+    "xp_layernorm_bwd_workspace_bytes": (sz, [i64, i64]),
+    "xp_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i64, i64, i32, vp, sz, vp]),
+    "xp_attn_workspace_bytes": (sz, [i32, i64, i64, i64, i64, i64]),
+    "xp_attn_fwd": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "xp_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "xp_im2col": (i32, [vp, vp, i64, i64, i64, i64, i32, vp]),
+    "xp_vip_proxy_rows": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "xp_vip_embed_bwd_workspace_bytes": (sz, [i64, i64, i64, i64]),
+    "xp_vip_embed_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, vp, sz, vp]),
+    "xp_text_embed_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "xp_text_embed_bwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, vp]),
+    "xp_argmax_rows": (i32, [vp, vp, i64, i64, vp]),
+    "xp_gather_rows": (i32, [vp, vp, vp, i64, i64, i64, i32, vp]),
+    "xp_scatter_rows": (i32, [vp, vp, vp, i64, i64, i64, i32, vp]),
+    "xp_l2norm_fwd": (i32, [vp, vp, vp, i64, i64, i32, vp]),
+    "xp_l2norm_bwd": (i32, [vp, vp, vp, vp, i64, i64, i32, vp]),
+    "xp_cast": (i32, [vp, vp, i64, i32, vp]),
+    "xp_cast_back": (i32, [vp, vp, i64, i32, i32, vp]),
+    "xp_nce_loss_workspace_bytes": (sz, [i64, i64]),
+    "xp_nce_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, sz, vp]),
+    "xp_probe_mfma_bf16": (i32, [vp, vp, vp, vp]),
+    "xp_probe_mfma_f32": (i32, [vp, vp, vp, vp]),
+    "xp_probe_tr16": (i32, [vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises RuntimeError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C xpretrain_amd/csrc`.  xpretrain_amd has no CPU / eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        missing = [n for n in SIGNATURES if not hasattr(l, n)]
+        if missing:
+            raise RuntimeError(f"{LIB_PATH} is missing C-ABI symbols: {missing}")
+        for n, (res, args) in SIGNATURES.items():
+            fn = getattr(l, n)
+            fn.restype, fn.argtypes = res, args
+        if l.xp_abi_version() != 1:
+            raise RuntimeError(f"ABI version mismatch: library {l.xp_abi_version()} != binding 1")
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().xp_last_error().decode()}")

@@ -1,0 +1,111 @@
+// Shared device/host helpers for the gfx950 kernels of libxpretrain_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/xpretrain_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ------------------------------------------------------------------------------------------ errors
+void xp_set_error(const char* fmt, ...);   // thread-local message (common.cpp)
+
+#define XP_REQUIRE(cond, ...)                                  \
+  do {                                                         \
+    if (!(cond)) { xp_set_error(__VA_ARGS__); return XP_ERR_ARG; } \
+  } while (0)
+
+#define XP_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      xp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return XP_ERR_LAUNCH;                                                     \
+    }                                                                           \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------ scalars
+template <typename T> struct DT;
+template <> struct DT<bf16_t> { static constexpr int id = XP_BF16; };
+template <> struct DT<float>  { static constexpr int id = XP_F32; };
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+
+// 4 consecutive elements <-> f32x4
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+  float s = 1.0f / (1.0f + __expf(-1.702f * x));
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+// ------------------------------------------------------------------------------------------ wave ops
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ MFMA
+// D[i][j] += sum_k A[i][k] B[k][j] on 16x16 tiles.  Lane l = (i16 = l & 15, g = l >> 4).
+//   bf16 (16x16x32): the lane's 16-byte fragment holds k = 8g .. 8g+7 for row/col i16.
+//   f32  (16x16x4, issued 4x): fragment holds 4 floats; MFMA e uses element e, i.e. k = 4g + e.
+// Any k permutation is fine as long as A and B fragments use the same one -- every loader below does.
+// C/D layout (both): lane holds D[row = 4g + r][col = i16], r = 0..3.
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float>  { typedef f32x4 type; };
+
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------ LDS tiles
+// Row-major tiles with 128-byte rows ([rows][8 x 16 B chunks]).  XOR swizzle on the 16-byte chunk
+// index, conflict-free both for ds_read_b128 of a 16-row x 16-byte column (MFMA k-contiguous
+// fragments) and for ds_read_b64_tr_b16 of 8 consecutive rows x 32 bytes (transposed fragments).
+__device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int tile128_off(int row, int chunk16) { return row * 128 + ((chunk16 ^ swz128(row)) << 4); }
+
+// LDS transpose read: each lane passes the address of 4 contiguous 16-bit elements; within each
+// 16-lane group the 16x4 elements form a [4][16] matrix (lanes 4j..4j+3 supply row j) and lane i gets
+// column i: result[j] = element (i & 3) of the chunk supplied by lane 4j + (i >> 2).   (probe.hip pins it)
+__device__ __forceinline__ i16x4 lds_read_tr16(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) i16x4*)(lds_ptr));
+}

@@ -1,0 +1,374 @@
+// MFMA GEMM family for gfx950:  C[M,N] = epilogue( sum_k A(m,k) B(n,k) ).
+//
+// One kernel template covers every dense contraction on the CLIP-ViP path (forward linears, dX, dW, the
+// patch-embedding conv-as-GEMM, projections, the loss logits) -- see include/xpretrain_hip.h.
+//
+// Tiling (wave64, 16x16 MFMA tiles): 128(M) x 128(N) block, 128 BYTES of k per stage (64 bf16 / 32 f32),
+// 4 waves in 2x2, each wave a 64x64 sub-tile = 4x4 accumulators of f32x4.  Operands are staged
+// global -> registers -> LDS (double-buffered, loads of stage s+1 in flight during the MFMAs of stage s).
+// The MFMA A operand is the N side (weights) and the B operand the M side (activations): the
+// accumulator lane then owns 4 CONSECUTIVE n for one m, so the epilogue is a 4-wide vector op
+// (bias / residual / activation) and an 8-byte (bf16) or 16-byte (f32) store.
+//
+// k-strided operands (dX: W[n][k] with contraction over n; dW: dY[m][n], X[m][k] with contraction over m)
+// are NOT transposed in memory: they are staged as [k][row] tiles and read with ds_read_b64_tr_b16
+// (bf16) / ds_read_b32 (f32), which deliver exactly the MFMA fragment.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKB = 128;   // BKB: bytes of k per stage
+constexpr int NT = 256;
+constexpr int TILE_BYTES = 128 * 128;          // one operand tile per stage (16 KiB)
+
+struct Remap {
+  int64_t grp, stride, off;
+  __device__ __forceinline__ int64_t operator()(int64_t r) const {
+    return grp == 0 ? r : (r / grp) * stride + off + (r % grp);
+  }
+};
+
+struct KParams {
+  const void* A; const void* B; void* C;
+  int64_t M, N, K, lda, ldb, ldc;
+  Remap amap, cmap;
+  int epilogue, out_f32;
+  int64_t k_per_split;
+  const float* bias; float scale; int64_t scale_cols;
+  const void* resid; int64_t ldr;
+  void* aux; int64_t ldaux;
+  const float* tab1; const float* tab2; int64_t tab_L;
+  int tiles_m, tiles_n;
+};
+
+// ---- staging: global -> registers (4 x 16 B per thread per operand) -------------------------------
+// k-contiguous operand: tile = [128 rows][128 B of k].
+template <typename T>
+__device__ __forceinline__ void gload_kc(u32x4 (&r)[4], const T* base, int64_t ld, int64_t row0, int64_t rows,
+                                         int64_t k0, int64_t kend, const Remap& map, int tid) {
+  constexpr int EPC = 16 / sizeof(T);           // elements per 16-byte chunk
+  const int c = tid & 7, rr = tid >> 3;
+  const int64_t k = k0 + c * EPC;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t row = row0 + rr + 32 * j;
+    if (row < rows && k < kend)
+      r[j] = *reinterpret_cast<const u32x4*>(base + map(row) * ld + k);
+    else
+      r[j] = u32x4{0, 0, 0, 0};
+  }
+}
+template <typename T>
+__device__ __forceinline__ void lstore_kc(char* tile, const u32x4 (&r)[4], int tid) {
+  const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rr + 32 * j;
+    *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = r[j];
+  }
+}
+
+// k-strided operand: storage [k][row]; tile = [KE k-rows][128 rows]  (KE = 64 bf16 / 32 f32).
+//   bf16: 256-byte k-rows, 32-byte blocks (16 rows) XOR-swizzled by f(k) = (k&3) | ((k>>3)&1)<<2
+//   f32 : 512-byte k-rows, column XOR ((k>>2)&1)<<4
+__device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <typename T>
+__device__ __forceinline__ void gload_ks(u32x4 (&r)[4], const T* base, int64_t ld, int64_t row0, int64_t rows,
+                                         int64_t k0, int64_t kend, const Remap& map, int tid) {
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int CPR = 128 / EPC;                // chunks per k-row: 16 (bf16) / 32 (f32)
+  constexpr int KSTEP = NT / CPR;               // k-rows covered per pass: 16 / 8
+  const int c = tid % CPR, kr = tid / CPR;
+  const int64_t row = row0 + c * EPC;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t k = k0 + kr + KSTEP * j;
+    if (k < kend && row < rows)
+      r[j] = *reinterpret_cast<const u32x4*>(base + map(k) * ld + row);
+    else
+      r[j] = u32x4{0, 0, 0, 0};
+  }
+}
+template <typename T>
+__device__ __forceinline__ void lstore_ks(char* tile, const u32x4 (&r)[4], int tid) {
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int CPR = 128 / EPC;
+  constexpr int KSTEP = NT / CPR;
+  const int c = tid % CPR, kr0 = tid / CPR;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kr = kr0 + KSTEP * j;
+    int off;
+    if (sizeof(T) == 2) off = kr * 256 + ((((c >> 1) ^ ks_f(kr)) << 5) | ((c & 1) << 4));
+    else                off = kr * 512 + (((c * 4) ^ (((kr >> 2) & 1) << 4)) << 2);
+    *reinterpret_cast<u32x4*>(tile + off) = r[j];
+  }
+}
+
+// ---- fragments: LDS -> registers ------------------------------------------------------------------
+// ot: 16-row sub-tile index (0..7) inside the 128-row tile; ks: 64-byte k super-step (0..1).
+template <typename T, bool KS>
+__device__ __forceinline__ typename Frag<T>::type lfrag(const char* tile, int ot, int ks, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (!KS) {
+    const int row = ot * 16 + i;
+    return *reinterpret_cast<const typename Frag<T>::type*>(tile + tile128_off(row, ks * 4 + g));
+  } else if constexpr (sizeof(T) == 2) {
+    // two transpose reads: k = ks*32 + 8g + {0..3}, {4..7}; lane supplies k-row (i>>2), 4 rows at (i&3)*4
+    const int f = (i >> 2) | ((g & 1) << 2);
+    const int kr = ks * 32 + g * 8 + (i >> 2);
+    const char* p = tile + kr * 256 + ((ot ^ f) << 5) + ((i & 3) << 3);
+    i16x4 lo = lds_read_tr16(p);
+    i16x4 hi = lds_read_tr16(p + 4 * 256);
+    typedef __attribute__((ext_vector_type(8))) short i16x8;
+    i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    f32x4 v;
+    const int col = (ot * 16 + i) ^ ((g & 1) << 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kr = ks * 16 + 4 * g + e;
+      v[e] = *reinterpret_cast<const float*>(tile + kr * 512 + col * 4);
+    }
+    return v;
+  }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+template <typename T, bool AKS, bool BKS>
+__global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto sA = [&](int s) -> char* { return smem + (2 * s) * TILE_BYTES; };
+  auto sB = [&](int s) -> char* { return smem + (2 * s + 1) * TILE_BYTES; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: consecutive tile ids land on the same XCD (block b runs on XCD b % 8),
+  // so tiles sharing an activation row-panel share one L2.
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  constexpr int KE = BKB / sizeof(T);
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int nk = (int)((kend - kbeg + KE - 1) / KE);
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+  const Remap ident{0, 0, 0};
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int64_t k0) {
+    if constexpr (AKS) gload_ks<T>(ra, A, p.lda, m0, p.M, k0, kend, p.amap, tid);
+    else               gload_kc<T>(ra, A, p.lda, m0, p.M, k0, kend, p.amap, tid);
+    if constexpr (BKS) gload_ks<T>(rb, B, p.ldb, n0, p.N, k0, kend, ident, tid);
+    else               gload_kc<T>(rb, B, p.ldb, n0, p.N, k0, kend, ident, tid);
+  };
+  auto lstore = [&](int s) {
+    if constexpr (AKS) lstore_ks<T>(sA(s), ra, tid); else lstore_kc<T>(sA(s), ra, tid);
+    if constexpr (BKS) lstore_ks<T>(sB(s), rb, tid); else lstore_kc<T>(sB(s), rb, tid);
+  };
+
+  if (nk > 0) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int s = kt & 1;
+    if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * KE);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename Frag<T>::type fw[4], fx[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fw[t] = lfrag<T, BKS>(sB(s), wn * 4 + t, ks, lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fx[t] = lfrag<T, AKS>(sA(s), wm * 4 + t, ks, lane);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    if (kt + 1 < nk) lstore(s ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns n = nb + 0..3 for row m -------------------------------------------------
+  const int i16 = lane & 15, g = lane >> 4;
+  const int ep = p.epilogue;
+  float* Cf = reinterpret_cast<float*>(p.C);
+  T* Ct = reinterpret_cast<T*>(p.C);
+  if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int64_t m = m0 + wm * 64 + mt * 16 + i16;
+    if (m >= p.M) continue;
+    const int64_t crow = p.cmap(m);
+    int64_t tt = 0, ll = 0;
+    if (ep == XP_EPI_PATCH) {
+      const int64_t w = p.cmap.grp ? (m % p.cmap.grp) : m;
+      tt = w / p.tab_L; ll = w % p.tab_L;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int64_t n = n0 + wn * 64 + nt * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[nt][mt];
+      if (ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID) {
+        const f32x4 b = load4(p.bias + n);
+        v += b;
+      }
+      if (ep == XP_EPI_BIAS_QSCALE) {
+        if (n < p.scale_cols) v *= p.scale;
+      } else if (ep == XP_EPI_SCALE) {
+        v *= p.scale;
+      } else if (ep == XP_EPI_BIAS_GELU) {
+        if (p.out_f32) store4(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
+        else           store4(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+      } else if (ep == XP_EPI_BIAS_RESID) {
+        v += load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+      } else if (ep == XP_EPI_GELU_BWD) {
+        const f32x4 pre = load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(pre[e]);
+      } else if (ep == XP_EPI_PATCH) {
+        v += load4(p.tab1 + tt * p.N + n);
+        v += load4(p.tab2 + ll * p.N + n);
+      }
+      if (p.out_f32) store4(Cf + crow * p.ldc + n, v);
+      else           store4(Ct + crow * p.ldc + n, v);
+    }
+  }
+}
+
+template <typename T>
+int launch(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
+  const size_t lds = 4 * TILE_BYTES;
+  if (!d->a_kstrided && !d->b_kstrided)      gemm_kernel<T, false, false><<<grid, NT, lds, st>>>(kp);
+  else if (!d->a_kstrided && d->b_kstrided)  gemm_kernel<T, false, true><<<grid, NT, lds, st>>>(kp);
+  else if (d->a_kstrided && d->b_kstrided)   gemm_kernel<T, true, true><<<grid, NT, lds, st>>>(kp);
+  else                                       gemm_kernel<T, true, false><<<grid, NT, lds, st>>>(kp);
+  return 0;
+}
+
+// ---- split-K slab reduce, column sums ---------------------------------------------------------------
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n4,
+                                     int splits, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 s = accumulate ? reinterpret_cast<const f32x4*>(out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) s += reinterpret_cast<const f32x4*>(slabs)[(int64_t)z * n4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+constexpr int CS_ROWS = 64;    // rows per colsum block
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
+                                      float* __restrict__ part) {
+  // block: 64 threads x 4 columns each = 256 columns; gridDim.y row chunks
+  const int64_t c = ((int64_t)blockIdx.x * 64 + threadIdx.x) * 4;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+  const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0; r < r1; ++r) s += load4(X + r * ldx + c);
+  store4(part + (int64_t)blockIdx.y * cols + c, s);
+}
+
+}  // namespace
+
+extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
+  XP_REQUIRE(d && d->A && d->B && d->C, "xp_gemm: null operand");
+  XP_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "xp_gemm: empty problem M=%lld N=%lld K=%lld",
+             (long long)d->M, (long long)d->N, (long long)d->K);
+  XP_REQUIRE(d->in_dtype == XP_BF16 || d->in_dtype == XP_F32, "xp_gemm: bad in_dtype %d", d->in_dtype);
+  XP_REQUIRE(d->out_dtype == d->in_dtype || d->out_dtype == XP_F32, "xp_gemm: bad out_dtype %d", d->out_dtype);
+  const int esz = d->in_dtype == XP_BF16 ? 2 : 4;
+  const int epc = 16 / esz;
+  // 16-byte chunks along the contiguous dimension of each operand
+  const int64_t a_contig = d->a_kstrided ? d->M : d->K, b_contig = d->b_kstrided ? d->N : d->K;
+  XP_REQUIRE(a_contig % epc == 0 && b_contig % epc == 0 && d->lda % epc == 0 && d->ldb % epc == 0,
+             "xp_gemm: contiguous extents / leading dims must be multiples of %d elements", epc);
+  XP_REQUIRE(d->N % 4 == 0 && d->ldc % 4 == 0, "xp_gemm: N and ldc must be multiples of 4");
+  XP_REQUIRE(((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) % 16 == 0, "xp_gemm: operands must be 16-byte aligned");
+  const int ep = d->epilogue;
+  XP_REQUIRE(ep >= XP_EPI_NONE && ep <= XP_EPI_SCALE, "xp_gemm: bad epilogue %d", ep);
+  if (ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID)
+    XP_REQUIRE(d->bias, "xp_gemm: epilogue %d needs bias", ep);
+  if (ep == XP_EPI_BIAS_RESID || ep == XP_EPI_GELU_BWD) XP_REQUIRE(d->resid && d->ldr % 4 == 0, "xp_gemm: epilogue %d needs resid", ep);
+  if (ep == XP_EPI_BIAS_GELU) XP_REQUIRE(d->aux && d->ldaux % 4 == 0, "xp_gemm: epilogue BIAS_GELU needs aux");
+  if (ep == XP_EPI_PATCH) XP_REQUIRE(d->tab1 && d->tab2 && d->tab_L > 0, "xp_gemm: epilogue PATCH needs tab1/tab2/tab_L");
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  if (split > 1) XP_REQUIRE(ep == XP_EPI_NONE && d->out_dtype == XP_F32 && d->c_grp == 0 && d->ldc == d->N,
+                            "xp_gemm: split_k needs EPI_NONE, f32 output, dense C");
+
+  KParams kp;
+  kp.A = d->A; kp.B = d->B; kp.C = d->C;
+  kp.M = d->M; kp.N = d->N; kp.K = d->K; kp.lda = d->lda; kp.ldb = d->ldb; kp.ldc = d->ldc;
+  kp.amap = Remap{d->a_grp, d->a_grp_stride, d->a_off};
+  kp.cmap = Remap{d->c_grp, d->c_grp_stride, d->c_off};
+  kp.epilogue = ep; kp.out_f32 = d->out_dtype == XP_F32;
+  const int ke = BKB / esz;
+  kp.k_per_split = cdiv(cdiv(d->K, split), ke) * ke;
+  kp.bias = d->bias; kp.scale = d->scale; kp.scale_cols = d->scale_cols;
+  kp.resid = d->resid; kp.ldr = d->ldr; kp.aux = d->aux; kp.ldaux = d->ldaux;
+  kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
+  kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
+  const int zsplits = (int)cdiv(d->K, kp.k_per_split);
+  XP_REQUIRE(split == 1 || zsplits == split, "xp_gemm: split_k=%d leaves empty slabs for K=%lld (use <= %d)",
+             split, (long long)d->K, zsplits);
+  dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->in_dtype == XP_BF16) launch<bf16_t>(d, kp, grid, st);
+  else                        launch<float>(d, kp, grid, st);
+  XP_CHECK_LAUNCH("xp_gemm");
+  return XP_OK;
+}
+
+extern "C" int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32_t splits, int32_t accumulate,
+                                void* stream) {
+  XP_REQUIRE(slabs && out && n > 0 && n % 4 == 0 && splits >= 1, "xp_splitk_reduce: bad arguments");
+  const int64_t n4 = n / 4;
+  int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
+  splitk_reduce_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(slabs, out, n4, splits, accumulate);
+  XP_CHECK_LAUNCH("xp_splitk_reduce");
+  return XP_OK;
+}
+
+extern "C" size_t xp_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  return (size_t)(cdiv(rows, CS_ROWS) * cols * sizeof(float));
+}
+
+extern "C" int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* out,
+                         int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  XP_REQUIRE(X && out && rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0, "xp_colsum: bad arguments");
+  XP_REQUIRE(workspace && workspace_bytes >= xp_colsum_workspace_bytes(rows, cols), "xp_colsum: workspace too small");
+  const int chunks = (int)cdiv(rows, CS_ROWS);
+  dim3 grid((unsigned)cdiv(cols, 256), chunks);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 64, 0, st>>>((const bf16_t*)X, rows, cols, ldx, part);
+  else                  colsum_partial_kernel<float><<<grid, 64, 0, st>>>((const float*)X, rows, cols, ldx, part);
+  XP_CHECK_LAUNCH("xp_colsum(partial)");
+  return xp_splitk_reduce(part, out, cols, chunks, accumulate, stream);
+}

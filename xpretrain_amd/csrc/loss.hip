@@ -1,0 +1,125 @@
+// NCELearnableTempLoss (optimization/loss.py:134-141) forward AND gradient in one call, fp32 throughout:
+//   A = exp(ls) * V T^T                     [n,n]   (V, T: gathered unit-norm features [n,d])
+//   loss = mean_i(lse_j A_ij - A_ii) + mean_j(lse_i A_ij - A_jj)
+//   G = dloss/dA = (softmax_rows(A) + softmax_cols(A) - 2 I) / n
+//   dV = exp(ls) G T ;  dT = exp(ls) G^T V ;  d ls = sum(G * A)
+// n = world_size * local_batch is small (64 at 8 GPUs x 8 pairs), so this is latency- not FLOP-bound:
+// plain fp32 FMA tiles (bit-stable, no bf16 rounding on the logits that are multiplied by ~100).
+#include "common.h"
+
+namespace {
+
+// C[i][j] = alpha * sum_k X(i,k) Y(k,j), generic strides; 32x32 tile, 256 threads, 2x2 per thread.
+__global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restrict__ X, int64_t sxi, int64_t sxk,
+                                                            const float* __restrict__ Y, int64_t syk, int64_t syj,
+                                                            float* __restrict__ C, int64_t ldc, int I, int J, int K,
+                                                            const float* __restrict__ log_scale) {
+  __shared__ float xs[32][33], ys[32][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      // xs[r][c] = X(i0 + r, k0 + c) ; ys[r][c] = Y(k0 + r, j0 + c)
+      xs[r][c] = (i0 + r < I && k0 + c < K) ? X[(int64_t)(i0 + r) * sxi + (int64_t)(k0 + c) * sxk] : 0.f;
+      ys[r][c] = (k0 + r < K && j0 + c < J) ? Y[(int64_t)(k0 + r) * syk + (int64_t)(j0 + c) * syj] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float a0 = xs[ty][k], a1 = xs[ty + 16][k], b0 = ys[k][tx], b1 = ys[k][tx + 16];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+  const float alpha = log_scale ? expf(*log_scale) : 1.0f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+      if (i < I && j < J) C[(int64_t)i * ldc + j] = alpha * acc[a][b];
+    }
+}
+
+// blocks 0..n-1: row i -> lse_r[i]; blocks n..2n-1: column j -> lse_c[j]   (one wave each)
+__global__ void lse_kernel(const float* __restrict__ A, float* __restrict__ lse_r, float* __restrict__ lse_c, int n) {
+  const int lane = threadIdx.x;
+  const bool col = blockIdx.x >= n;
+  const int idx = col ? blockIdx.x - n : blockIdx.x;
+  const int64_t step = col ? n : 1, base = col ? idx : (int64_t)idx * n;
+  float m = -INFINITY;
+  for (int t = lane; t < n; t += 64) m = fmaxf(m, A[base + t * step]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int t = lane; t < n; t += 64) s += expf(A[base + t * step] - m);
+  s = wave_sum(s);
+  if (lane == 0) (col ? lse_c : lse_r)[idx] = m + logf(s);
+}
+
+// block i: G[i][:] ; part[i] = (loss_i, dls_i)
+__global__ void grad_kernel(const float* __restrict__ A, const float* __restrict__ lse_r, const float* __restrict__ lse_c,
+                            float* __restrict__ G, float* __restrict__ part, int n) {
+  const int lane = threadIdx.x, i = blockIdx.x;
+  const float inv = 1.0f / (float)n, lr = lse_r[i];
+  float dls = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float a = A[(int64_t)i * n + j];
+    float g = (expf(a - lr) + expf(a - lse_c[j]) - (i == j ? 2.0f : 0.0f)) * inv;
+    G[(int64_t)i * n + j] = g;
+    dls += g * a;
+  }
+  dls = wave_sum(dls);
+  if (lane == 0) {
+    const float aii = A[(int64_t)i * n + i];
+    part[2 * i] = ((lr - aii) + (lse_c[i] - aii)) * inv;
+    part[2 * i + 1] = dls;
+  }
+}
+
+__global__ void finish_kernel(const float* __restrict__ part, float* loss, float* d_ls, int n) {
+  const int lane = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int i = lane; i < n; i += 64) { a += part[2 * i]; b += part[2 * i + 1]; }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { *loss = a; *d_ls = b; }
+}
+
+}  // namespace
+
+extern "C" size_t xp_nce_loss_workspace_bytes(int64_t n, int64_t d) {
+  (void)d;
+  return (size_t)(2 * n * n + 4 * n) * sizeof(float);   // A, G, lse_r, lse_c, part[2n]
+}
+
+extern "C" int xp_nce_loss(const float* vis, const float* txt, const float* log_scale, float* loss,
+                           float* d_vis, float* d_txt, float* d_log_scale, int64_t n, int64_t d,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  XP_REQUIRE(vis && txt && log_scale && loss && d_vis && d_txt && d_log_scale, "xp_nce_loss: null pointer");
+  XP_REQUIRE(n > 0 && d > 0 && n <= 16384, "xp_nce_loss: bad sizes n=%lld d=%lld", (long long)n, (long long)d);
+  XP_REQUIRE(workspace && workspace_bytes >= xp_nce_loss_workspace_bytes(n, d), "xp_nce_loss: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* A = (float*)workspace;
+  float* G = A + n * n;
+  float* lse_r = G + n * n;
+  float* lse_c = lse_r + n;
+  float* part = lse_c + n;
+  const int N = (int)n, D = (int)d;
+  dim3 gnn((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32)), gnd((unsigned)cdiv(d, 32), (unsigned)cdiv(n, 32));
+  // A[i][j] = e^ls sum_k V[i][k] T[j][k]
+  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, txt, 1, d, A, n, N, N, D, log_scale);
+  XP_CHECK_LAUNCH("xp_nce_loss(logits)");
+  lse_kernel<<<(unsigned)(2 * n), 64, 0, st>>>(A, lse_r, lse_c, N);
+  XP_CHECK_LAUNCH("xp_nce_loss(lse)");
+  grad_kernel<<<(unsigned)n, 64, 0, st>>>(A, lse_r, lse_c, G, part, N);
+  XP_CHECK_LAUNCH("xp_nce_loss(grad)");
+  finish_kernel<<<1, 64, 0, st>>>(part, loss, d_log_scale, N);
+  XP_CHECK_LAUNCH("xp_nce_loss(finish)");
+  // dV[i][k] = e^ls sum_j G[i][j] T[j][k] ;  dT[j][k] = e^ls sum_i G[i][j] V[i][k]
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G, n, 1, txt, d, 1, d_vis, d, N, D, N, log_scale);
+  XP_CHECK_LAUNCH("xp_nce_loss(dV)");
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G, 1, n, vis, d, 1, d_txt, d, N, D, N, log_scale);
+  XP_CHECK_LAUNCH("xp_nce_loss(dT)");
+  return XP_OK;
+}

@@ -1,0 +1,266 @@
+"""Tensor-level wrappers over the C ABI (no autograd here -- see ``functional.py``).
+
+Every function takes CUDA(HIP) tensors, allocates outputs with torch (device memory is
+PyTorch's job), passes raw ``data_ptr()``s plus the current HIP stream to
+``libxpretrain_hip.so`` and raises ``RuntimeError`` with ``xp_last_error()`` on failure.
+Nothing here computes with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.XP_BF16, torch.float32: L.XP_F32}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}; xpretrain_amd computes in bfloat16 or float32")
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor -- xpretrain_amd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """Grow-only per-(device, stream, tag) scratch buffer.  Kernels on one stream execute in
+    order, so consecutive users of the same tag never overlap."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------- GEMM
+def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
+         a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
+         scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
+         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None) -> torch.Tensor:
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc."""
+    _chk(A, "A"); _chk(B, "B", A.dtype)
+    out_dtype = out_dtype or A.dtype
+    if split_k > 1:
+        out = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device) if out is None else out
+        out_dtype = torch.float32
+    elif out is None:
+        out = torch.empty((out_rows or M, N), dtype=out_dtype, device=A.device)
+    d = L.XpGemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda = lda if lda is not None else (M if a_kstrided else K)
+    d.ldb = ldb if ldb is not None else (N if b_kstrided else K)
+    d.ldc = ldc if ldc is not None else N
+    d.a_kstrided, d.b_kstrided = int(a_kstrided), int(b_kstrided)
+    d.in_dtype, d.out_dtype = _dt(A), _DT[out_dtype]
+    d.epilogue, d.split_k = epilogue, split_k
+    d.a_grp, d.a_grp_stride, d.a_off = a_remap
+    d.c_grp, d.c_grp_stride, d.c_off = c_remap
+    d.bias = 0 if bias is None else _chk(bias, "bias", torch.float32).data_ptr()
+    d.scale, d.scale_cols = float(scale), scale_cols
+    d.resid = 0 if resid is None else _chk(resid, "resid", A.dtype).data_ptr()
+    d.ldr = ldr if ldr is not None else N
+    d.aux = 0 if aux is None else _chk(aux, "aux", out_dtype).data_ptr()
+    d.ldaux = ldaux if ldaux is not None else N
+    d.tab1 = 0 if tab1 is None else _chk(tab1, "tab1", torch.float32).data_ptr()
+    d.tab2 = 0 if tab2 is None else _chk(tab2, "tab2", torch.float32).data_ptr()
+    d.tab_L = tab_L
+    L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
+    return out
+
+
+def splitk_reduce(slabs: torch.Tensor, out: torch.Tensor, accumulate=False) -> torch.Tensor:
+    n = out.numel()
+    L.check(L.lib().xp_splitk_reduce(_p(slabs), _p(out), n, slabs.numel() // n, int(accumulate), _stream()),
+            "xp_splitk_reduce")
+    return out
+
+
+def colsum(X: torch.Tensor, rows: int, cols: int, ldx=None, out=None, accumulate=False) -> torch.Tensor:
+    _chk(X, "X")
+    out = torch.empty(cols, dtype=torch.float32, device=X.device) if out is None else out
+    nb = L.lib().xp_colsum_workspace_bytes(rows, cols)
+    ws = workspace(nb, X.device, "colsum")
+    L.check(L.lib().xp_colsum(_p(X), rows, cols, ldx or cols, _dt(X), _p(out), int(accumulate), _p(ws), ws.numel(),
+                              _stream()), "xp_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows: int, cols: int, ldx=None,
+                  eps: float = 1e-5):
+    _chk(x, "x"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
+    y = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().xp_layernorm_fwd(_p(x), ldx or cols, _p(gamma), _p(beta), _p(y), cols, _p(mean), _p(rstd),
+                                     rows, cols, eps, _dt(x), _stream()), "xp_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, dres=None, dx=None, lddx=None,
+                  dgamma=None, dbeta=None, accumulate=False):
+    _chk(dy, "dy"); _chk(x, "x", dy.dtype)
+    dx = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device) if dx is None else dx
+    dgamma = torch.empty(cols, dtype=torch.float32, device=dy.device) if dgamma is None else dgamma
+    dbeta = torch.empty(cols, dtype=torch.float32, device=dy.device) if dbeta is None else dbeta
+    nb = L.lib().xp_layernorm_bwd_workspace_bytes(rows, cols)
+    ws = workspace(nb, dy.device, "ln")
+    L.check(L.lib().xp_layernorm_bwd(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
+                                     _p(dres), cols, _p(dx), lddx or cols, _p(dgamma), _p(dbeta), int(accumulate),
+                                     rows, cols, _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------------------- probes
+def probe_mfma_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    c = torch.empty((64, 4), dtype=torch.float32, device=a.device)
+    L.check(L.lib().xp_probe_mfma_bf16(_p(a), _p(b), _p(c), _stream()), "xp_probe_mfma_bf16")
+    return c
+
+
+def probe_mfma_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    c = torch.empty((64, 4), dtype=torch.float32, device=a.device)
+    L.check(L.lib().xp_probe_mfma_f32(_p(a), _p(b), _p(c), _stream()), "xp_probe_mfma_f32")
+    return c
+
+
+def probe_tr16(data: torch.Tensor, lane_off: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((64, 4), dtype=torch.int16, device=data.device)
+    L.check(L.lib().xp_probe_tr16(_p(data), _p(lane_off), _p(out), _stream()), "xp_probe_tr16")
+    return out
+
+
+# --------------------------------------------------------------------------------------- embeddings / glue
+def im2col(video: torch.Tensor, P: int, dtype) -> torch.Tensor:
+    """video fp32 [BT,3,H,W] -> [BT*(H/P)*(W/P), 3*P*P] in `dtype`."""
+    _chk(video, "video", torch.float32)
+    BT, Cc, H, W = video.shape
+    assert Cc == 3 and video.is_contiguous()
+    out = torch.empty((BT * (H // P) * (W // P), 3 * P * P), dtype=dtype, device=video.device)
+    L.check(L.lib().xp_im2col(_p(video), _p(out), BT, H, W, P, _DT[dtype], _stream()), "xp_im2col")
+    return out
+
+
+def vip_proxy_rows(class_emb, added_cls, pos, x, B, S, M, D):
+    L.check(L.lib().xp_vip_proxy_rows(_p(class_emb), _p(added_cls), _p(pos), _p(x), B, S, M, D, _dt(x), _stream()),
+            "xp_vip_proxy_rows")
+    return x
+
+
+def vip_embed_bwd(dx, B, M, T, Lp, D, want_time=True):
+    dev = dx.device
+    d_class = torch.empty(D, dtype=torch.float32, device=dev)
+    d_added = torch.empty((max(M - 1, 1), D), dtype=torch.float32, device=dev)
+    d_pos = torch.empty((1 + Lp, D), dtype=torch.float32, device=dev)
+    d_time = torch.empty((T, D), dtype=torch.float32, device=dev) if want_time else None
+    nb = L.lib().xp_vip_embed_bwd_workspace_bytes(B, T, Lp, D)
+    ws = workspace(nb, dev, "embed")
+    L.check(L.lib().xp_vip_embed_bwd(_p(dx), _p(d_class), _p(d_added), _p(d_pos), _p(d_time), B, M, T, Lp, D, _dt(dx), 0,
+                                     _p(ws), ws.numel(), _stream()), "xp_vip_embed_bwd")
+    return d_class, d_added[: M - 1], d_pos, d_time
+
+
+def text_embed_fwd(ids, tok, pos, dtype):
+    _chk(ids, "ids", torch.int64)
+    B, Lt = ids.shape
+    vocab, D = tok.shape
+    x = torch.empty((B * Lt, D), dtype=dtype, device=ids.device)
+    L.check(L.lib().xp_text_embed_fwd(_p(ids), _p(tok), _p(pos), _p(x), B, Lt, D, vocab, _DT[dtype], _stream()),
+            "xp_text_embed_fwd")
+    return x
+
+
+def text_embed_bwd(ids, dx, vocab, npos):
+    B, Lt = ids.shape
+    D = dx.shape[-1]
+    d_tok = torch.empty((vocab, D), dtype=torch.float32, device=dx.device)
+    d_pos = torch.zeros((npos, D), dtype=torch.float32, device=dx.device)
+    L.check(L.lib().xp_text_embed_bwd(_p(ids), _p(dx), _p(d_tok), _p(d_pos), B, Lt, D, vocab, _dt(dx), 0, _stream()),
+            "xp_text_embed_bwd")
+    return d_tok, d_pos
+
+
+def argmax_rows(ids):
+    B, Lt = ids.shape
+    idx = torch.empty(B, dtype=torch.int64, device=ids.device)
+    L.check(L.lib().xp_argmax_rows(_p(ids), _p(idx), B, Lt, _stream()), "xp_argmax_rows")
+    return idx
+
+
+def gather_rows(x, idx, B, S, D):
+    out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    L.check(L.lib().xp_gather_rows(_p(x), _p(idx), _p(out), B, S, D, _dt(x), _stream()), "xp_gather_rows")
+    return out
+
+
+def scatter_rows(dout, idx, B, S, D):
+    dx = torch.empty((B * S, D), dtype=dout.dtype, device=dout.device)
+    L.check(L.lib().xp_scatter_rows(_p(dout), _p(idx), _p(dx), B, S, D, _dt(dout), _stream()), "xp_scatter_rows")
+    return dx
+
+
+def l2norm_fwd(x, rows, cols):
+    y = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().xp_l2norm_fwd(_p(x), _p(y), _p(inv), rows, cols, _dt(x), _stream()), "xp_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv, rows, cols, dtype):
+    _chk(dy, "dy", torch.float32)
+    dx = torch.empty((rows, cols), dtype=dtype, device=dy.device)
+    L.check(L.lib().xp_l2norm_bwd(_p(dy), _p(y), _p(inv), _p(dx), rows, cols, _DT[dtype], _stream()), "xp_l2norm_bwd")
+    return dx
+
+
+def cast(src: torch.Tensor, dtype, out=None) -> torch.Tensor:
+    _chk(src, "src", torch.float32)
+    out = torch.empty(src.shape, dtype=dtype, device=src.device) if out is None else out
+    L.check(L.lib().xp_cast(_p(src), _p(out), src.numel(), _DT[dtype], _stream()), "xp_cast")
+    return out
+
+
+def cast_back(src: torch.Tensor, out=None, accumulate=False) -> torch.Tensor:
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device) if out is None else out
+    L.check(L.lib().xp_cast_back(_p(src), _p(out), src.numel(), _dt(src), int(accumulate), _stream()), "xp_cast_back")
+    return out
+
+
+# --------------------------------------------------------------------------------------- loss
+def nce_loss(vis: torch.Tensor, txt: torch.Tensor, log_scale: torch.Tensor):
+    """Returns (loss, d_vis, d_txt, d_log_scale) -- fp32 device tensors."""
+    _chk(vis, "vis", torch.float32); _chk(txt, "txt", torch.float32); _chk(log_scale, "log_scale", torch.float32)
+    n, d = vis.shape
+    dev = vis.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dls = torch.empty((), dtype=torch.float32, device=dev)
+    dv, dt = torch.empty_like(vis), torch.empty_like(txt)
+    nb = L.lib().xp_nce_loss_workspace_bytes(n, d)
+    ws = workspace(nb, dev, "loss")
+    L.check(L.lib().xp_nce_loss(_p(vis), _p(txt), _p(log_scale), _p(loss), _p(dv), _p(dt), _p(dls), n, d, _p(ws),
+                                ws.numel(), _stream()), "xp_nce_loss")
+    return loss, dv, dt, dls
