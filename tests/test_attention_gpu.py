@@ -1,0 +1,75 @@
+"""GPU: fused proxy / causal attention kernels vs the oracle's attention cores (fp64 on the kernel's own
+bf16 inputs), forward and backward, across the (M,N,L) shapes SURVEY.md §8c lists, ragged padding masks,
+the degenerate all-padded row, and a forced online-softmax rescale (large score spike in a late key tile)."""
+import pytest
+import torch
+
+from oracle import clipvip_oracle as O
+from tests.gpu_util import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(qkv, B, S, H):
+    q, k, v = qkv.view(B, S, 3, H, 64).double().unbind(2)          # [B,S,H,64]
+    return [t.transpose(1, 2) for t in (q, k, v)]                  # [B,H,S,64]
+
+
+def _run(B, H, size, S, pad_mask, seed, scale=1.0, spike=False, q_scale=1.0):
+    from xpretrain_amd import hip_ops as Hh
+    torch.manual_seed(seed)
+    qkv = (torch.randn(B * S, 3 * H * 64, device="cuda") * scale).to(torch.bfloat16)
+    if spike:   # one key late in the sequence dominates one query's row: forces m to jump at the last tile
+        v = qkv.view(B, S, 3, H, 64)
+        v[0, S - 1, 1, 0] = v[0, S // 2, 0, 0] * 6.0
+    out, stats = Hh.attn_fwd(qkv, B, S, H, size=size, pad_mask=pad_mask)
+    q, k, v = [t.requires_grad_() for t in _split(qkv, B, S, H)]
+    if size is not None:
+        ref = O.proxy_attention_core(q, k, v, size)
+    else:
+        ref = O.masked_attention_core(q, k, v, None if pad_mask is None else pad_mask.cpu().to(q.device))
+    refo = ref.transpose(1, 2).reshape(B * S, H * 64)
+    tag = f"attn B{B} H{H} size{size} S{S} pad{pad_mask is not None}"
+    e1 = report(tag + " fwd", out, refo, 1.2e-2)
+    dout = torch.randn(B * S, H * 64, device="cuda").to(torch.bfloat16)
+    refo.backward(dout.double())
+    dqkv = Hh.attn_bwd(qkv, out, dout, stats, B, S, H, size=size, pad_mask=pad_mask, q_scale=q_scale)
+    dq, dk, dv = [t.transpose(1, 2) for t in dqkv.view(B, S, 3, H, 64).double().unbind(2)]
+    e2 = report(tag + " dq", dq, q.grad * q_scale, 2e-2)
+    e3 = report(tag + " dk", dk, k.grad, 2e-2)
+    e4 = report(tag + " dv", dv, v.grad, 2e-2)
+    assert e1 <= 1.2e-2 and e2 <= 2e-2 and e3 <= 2e-2 and e4 <= 2e-2, tag
+    assert torch.isfinite(dqkv.float()).all()
+
+
+@pytest.mark.parametrize("size,B,H", [((4, 2, 49), 2, 2), ((4, 12, 196), 1, 2), ((1, 3, 5), 2, 1), ((4, 3, 70), 1, 3),
+                                      ((2, 5, 16), 2, 3), ((4, 1, 196), 1, 1), ((4, 2, 784), 1, 1), ((4, 32, 196), 1, 1)])
+def test_proxy_attention(size, B, H):
+    M, N, L = size
+    _run(B, H, size, M + N * L, None, seed=M + N + L)
+
+
+def test_proxy_attention_rescale_and_qscale():
+    _run(1, 2, (4, 3, 196), 4 + 3 * 196, None, seed=5, scale=2.0, spike=True, q_scale=0.125)
+
+
+@pytest.mark.parametrize("B,S,H,mode", [(3, 12, 2, "ragged"), (2, 32, 8, "ragged"), (2, 7, 1, "none"), (2, 77, 2, "ragged"),
+                                        (2, 16, 2, "allpad"), (1, 130, 1, "ragged")])
+def test_causal_attention(B, S, H, mode):
+    torch.manual_seed(S)
+    if mode == "none":
+        mask = None
+    else:
+        lens = torch.randint(1, S + 1, (B,)); lens[0] = S
+        mask = (torch.arange(S)[None] < lens[:, None]).long()
+        if mode == "allpad":
+            mask[1] = 0
+        mask = mask.cuda()
+    _run(B, H, None, S, mask, seed=S + 1)
+
+
+def test_attention_rejects_bad_shapes():
+    from xpretrain_amd import hip_ops as Hh
+    qkv = torch.zeros(10 * 3, 3 * 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="M\\+N\\*L"):
+        Hh.attn_fwd(qkv, 3, 10, 1, size=(4, 2, 2))

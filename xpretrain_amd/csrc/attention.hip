@@ -1,10 +1,507 @@
+// Fused attention for the CLIP-ViP path on gfx950 (wave64, 16x16x32 bf16 MFMA, head_dim = 64).
+//
+// Both attention flavours of the reference are one block-sparse problem family:
+//   PROXY  (CLIPAttention.forward2, modeling/CLIP_ViP.py:332-381): for every (batch b, head h, frame n) the
+//          "problem" has rows/cols R = [M proxy tokens | L tokens of frame n].  Frame rows see all R cols and
+//          are complete inside the problem.  Proxy rows see every frame's tokens: each problem contributes a
+//          partial (max, sum, unnormalised O) that a tiny merge kernel combines over n; the proxy x proxy
+//          block is counted in problem n == 0 only.  No repeat()/cat() copies of K/V are ever materialised.
+//   CAUSAL (CLIPAttention.forward text path :266-330): one problem per (b, h), R = S, key <= query, padded
+//          keys get the reference's additive finfo.min (so an all-padded row degenerates to uniform, as there).
+//
+// Data layout: qkv[B,S,3,H,64] exactly as the fused QKV GEMM writes it (128 contiguous bytes per
+// (token, head)); out/dout [B,S,H*64]; stats[B,H,S,2] = (row max, log row sum).
+//
+// Kernel structure (flash style, no S x S matrix in memory):
+//   fwd : workgroup = 64 query rows (4 waves x 16), loop over 64-key tiles staged in LDS (XOR-swizzled
+//         128-byte rows).  Scores are computed TRANSPOSED (S^T = K Q^T) so that each lane owns one query
+//         column: the online-softmax statistics are per-lane scalars and the bf16 P values are already the
+//         B-operand fragment of the P.V MFMA -- no cross-lane shuffles or LDS round trip for P.  V^T
+//         fragments come straight out of the row-major V tile through ds_read_b64_tr_b16.
+//   bwd : two passes, no atomics (deterministic).  dKV: workgroup = 64 keys, loops over query tiles
+//         (S = Q K^T orientation so P/dS are again B-operand fragments).  dQ: workgroup = 64 queries,
+//         loops over key tiles (transposed orientation).  Proxy-token partials are reduced over frames by
+//         a small kernel.
 #include "common.h"
-extern "C" size_t xp_attn_workspace_bytes(int32_t, int64_t, int64_t, int64_t, int64_t, int64_t) { return 0; }
-extern "C" int xp_attn_fwd(const void*, int64_t, void*, int64_t, float*, const int64_t*, int32_t, int64_t, int64_t, int64_t,
-                           int64_t, int64_t, int64_t, int32_t, void*, size_t, void*) {
-  xp_set_error("xp_attn_fwd: not built yet"); return XP_ERR_UNSUPPORTED;
+#include <math.h>
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int TQ = 64;            // rows per workgroup tile
+constexpr int TILE = 64 * 128;    // bytes of one [64][64] bf16 tile
+constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(float32).min, _expand_mask (:50-61)
+
+struct AP {
+  const bf16_t* qkv; int64_t ldqkv;
+  bf16_t* out; const bf16_t* dout; int64_t ldo;
+  bf16_t* dqkv;
+  float* stats;
+  const int64_t* pad;
+  int mode, B, H, S, M, N, L, R;
+  float q_scale;
+  float* ws0; float* ws1; float* ws2;   // fwd: partials | bwd: delta, dq partials, dkv partials
+};
+
+struct Prob {
+  int b, h, n;
+  __device__ __forceinline__ Prob(const AP& p, int idx) {
+    if (p.mode == XP_ATTN_PROXY) { n = idx % p.N; int bh = idx / p.N; h = bh % p.H; b = bh / p.H; }
+    else { n = 0; h = idx % p.H; b = idx / p.H; }
+  }
+};
+// problem row -> token index inside the sample
+__device__ __forceinline__ int tok_of(const AP& p, int n, int r) {
+  return (p.mode == XP_ATTN_PROXY && r >= p.M) ? p.M + n * p.L + (r - p.M) : r;
 }
-extern "C" int xp_attn_bwd(const void*, int64_t, const void*, const void*, int64_t, const float*, const int64_t*, void*, float,
-                           int32_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int32_t, void*, size_t, void*) {
-  xp_set_error("xp_attn_bwd: not built yet"); return XP_ERR_UNSUPPORTED;
+// may query row rq attend key row rk (both < R)?  padding is handled separately (finfo.min, still "attended")
+__device__ __forceinline__ bool allowed(const AP& p, int n, int rq, int rk) {
+  if (p.mode == XP_ATTN_PROXY) return !(rq < p.M && rk < p.M && n != 0);
+  return rk <= rq;
+}
+
+// ---- cooperative tile load: 64 problem rows x 64 bf16 (q, k or v slice `which`, or out/dout) -> LDS ---------
+__device__ __forceinline__ void load_tile_qkv(char* tile, const AP& p, const Prob& pr, int which, int row0, int tid) {
+  const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = rr + 32 * j, r = row0 + row;
+    u32x4 v = {0, 0, 0, 0};
+    if (r < p.R) {
+      const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
+      v = *reinterpret_cast<const u32x4*>(p.qkv + t * p.ldqkv + (int64_t)which * p.H * DH + pr.h * DH + c * 8);
+    }
+    *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = v;
+  }
+}
+__device__ __forceinline__ void load_tile_o(char* tile, const bf16_t* src, const AP& p, const Prob& pr, int row0, int tid) {
+  const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = rr + 32 * j, r = row0 + row;
+    u32x4 v = {0, 0, 0, 0};
+    if (r < p.R) {
+      const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
+      v = *reinterpret_cast<const u32x4*>(src + t * p.ldo + pr.h * DH + c * 8);
+    }
+    *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = v;
+  }
+}
+// per-lane register fragment of one row (as MFMA B operand: lane (j = row, g) holds d = 32kk + 8g .. +8)
+__device__ __forceinline__ void load_row_frag(bf16x8 (&f)[2], const bf16_t* rowptr, bool valid, int g) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    if (valid) f[kk] = *reinterpret_cast<const bf16x8*>(rowptr + kk * 32 + g * 8);
+    else f[kk] = __builtin_bit_cast(bf16x8, u32x4{0, 0, 0, 0});
+  }
+}
+// A-operand fragment, rows = tile rows (16-row sub-tile t), k = d  (ds_read_b128)
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int t, int kk, int lane) {
+  const int row = t * 16 + (lane & 15);
+  return *reinterpret_cast<const bf16x8*>(tile + tile128_off(row, kk * 4 + (lane >> 4)));
+}
+// A-operand fragment of the TRANSPOSED tile: rows = d (16-col sub-tile dt), k = tile rows
+//   k-slot e < 4 -> row (2c)*16 + 4g + e ; e >= 4 -> row (2c+1)*16 + 4g + e-4   (matches pack_p below)
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int dt, int c, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int r0 = (2 * c) * 16 + 4 * g + (i >> 2);
+  const int ch = dt * 2 + ((i & 3) >> 1), sub = (i & 1) << 3;
+  i16x4 lo = lds_read_tr16(tile + tile128_off(r0, ch) + sub);
+  i16x4 hi = lds_read_tr16(tile + tile128_off(r0 + 16, ch) + sub);
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+  i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_p(f32x4 a, f32x4 b) {
+  return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+}
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+constexpr int PART = 2 + DH;   // forward proxy partial: m, l, O[64]
+
+// ============================================================================================ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
+  char* sK = smem; char* sV = smem + TILE; unsigned char* sPad = reinterpret_cast<unsigned char*>(smem + 2 * TILE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+  const Prob pr(p, blockIdx.y);
+  const int qb = blockIdx.x * TQ;
+  const int rq = qb + wave * 16 + i16;            // this lane's query row (column of S^T)
+  const bool qvalid = rq < p.R;
+  const int64_t qtok = (int64_t)pr.b * p.S + tok_of(p, pr.n, qvalid ? rq : 0);
+
+  bf16x8 qf[2];
+  load_row_frag(qf, p.qkv + qtok * p.ldqkv + pr.h * DH, qvalid, g);
+
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+  float m = -INFINITY, l = 0.f;
+
+  int ntiles = (p.R + 63) / 64;
+  if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kb = kt * 64;
+    load_tile_qkv(sK, p, pr, 1, kb, tid);
+    load_tile_qkv(sV, p, pr, 2, kb, tid);
+    if (tid < 64) {
+      const int r = kb + tid;
+      sPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
+    }
+    __syncthreads();
+
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) s[t] = mma16(frag_rows(sK, t, kk, lane), qf[kk], s[t]);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kl = t * 16 + 4 * g + r, rk = kb + kl;
+        float v = s[t][r];
+        if (sPad[kl]) v = F32_MIN;
+        if (!(qvalid && rk < p.R && allowed(p, pr.n, rq, rk))) v = -INFINITY;
+        s[t][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = group_max(tmax);
+    const float mnew = fmaxf(m, tmax);
+    const float msafe = mnew == -INFINITY ? 0.f : mnew;
+    const float alpha = __expf(m - msafe);          // m = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __expf(s[t][r] - msafe); s[t][r] = e; psum += e; }
+    l = l * alpha + psum;
+    m = mnew;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+    const bf16x8 pf0 = pack_p(s[0], s[1]), pf1 = pack_p(s[2], s[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      o[dt] = mma16(frag_cols(sV, dt, 0, lane), pf0, o[dt]);
+      o[dt] = mma16(frag_cols(sV, dt, 1, lane), pf1, o[dt]);
+    }
+    __syncthreads();
+  }
+  l = group_sum(l);
+  if (!qvalid) return;
+  if (p.mode == XP_ATTN_PROXY && rq < p.M) {
+    float* part = p.ws0 + ((int64_t)blockIdx.y * p.M + rq) * PART;
+    if (g == 0) { part[0] = m; part[1] = l; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(part + 2 + dt * 16 + 4 * g, o[dt]);
+    return;
+  }
+  const float inv = 1.0f / l;
+  bf16_t* orow = p.out + qtok * p.ldo + pr.h * DH;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + 4 * g, o[dt] * inv);
+  if (g == 0) {
+    float* st = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, rq)) * 2;
+    st[0] = m; st[1] = __logf(l);
+  }
+}
+
+// merge the per-frame partials of the proxy query rows: grid = B*H*M, 64 lanes = d
+__global__ void attn_fwd_merge_kernel(AP p) {
+  const int d = threadIdx.x;
+  const int mrow = blockIdx.x % p.M, bh = blockIdx.x / p.M, h = bh % p.H, b = bh / p.H;
+  float mx = -INFINITY;
+  for (int n = 0; n < p.N; ++n) mx = fmaxf(mx, p.ws0[(((int64_t)bh * p.N + n) * p.M + mrow) * PART]);
+  float l = 0.f, acc = 0.f;
+  for (int n = 0; n < p.N; ++n) {
+    const float* part = p.ws0 + (((int64_t)bh * p.N + n) * p.M + mrow) * PART;
+    const float w = __expf(part[0] - mx);
+    l += part[1] * w; acc += part[2 + d] * w;
+  }
+  const int64_t tok = (int64_t)b * p.S + mrow;
+  p.out[tok * p.ldo + h * DH + d] = (bf16_t)(acc / l);
+  if (d == 0) { float* st = p.stats + (((int64_t)b * p.H + h) * p.S + mrow) * 2; st[0] = mx; st[1] = __logf(l); }
+}
+
+// ============================================================================================ backward
+// delta[b,h,s] = sum_d dO * O      (one thread per (token, head))
+__global__ void attn_delta_kernel(AP p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.S * p.H;
+  if (idx >= total) return;
+  const int h = (int)(idx % p.H);
+  const int64_t tok = idx / p.H;
+  const bf16_t* a = p.out + tok * p.ldo + h * DH;
+  const bf16_t* b = p.dout + tok * p.ldo + h * DH;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c * 8), y = *reinterpret_cast<const bf16x8*>(b + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
+  }
+  const int64_t bb = tok / p.S, ss = tok % p.S;
+  p.ws0[(bb * p.H + h) * p.S + ss] = s;
+}
+
+// dK, dV: workgroup = 64 key rows of one problem; loops over the problem's query tiles.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 3 * 64 * 4];
+  char* sQ = smem; char* sDO = smem + TILE;
+  float* sM = reinterpret_cast<float*>(smem + 2 * TILE); float* sLg = sM + 64; float* sDl = sLg + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+  const Prob pr(p, blockIdx.y);
+  const int kb = blockIdx.x * TQ;
+  const int rk = kb + wave * 16 + i16;            // this lane's key row (column of S)
+  const bool kvalid = rk < p.R;
+  const int64_t ktok = (int64_t)pr.b * p.S + tok_of(p, pr.n, kvalid ? rk : 0);
+  const bool kpad = kvalid && p.pad && p.pad[ktok] == 0;
+
+  bf16x8 kf[2], vf[2];
+  load_row_frag(kf, p.qkv + ktok * p.ldqkv + (int64_t)p.H * DH + pr.h * DH, kvalid, g);
+  load_row_frag(vf, p.qkv + ktok * p.ldqkv + (int64_t)2 * p.H * DH + pr.h * DH, kvalid, g);
+
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+
+  const int ntiles = (p.R + 63) / 64;
+  const int qt0 = p.mode == XP_ATTN_CAUSAL ? kb / 64 : 0;     // queries before the first key never see it
+  for (int qt = qt0; qt < ntiles; ++qt) {
+    const int qb = qt * 64;
+    load_tile_qkv(sQ, p, pr, 0, qb, tid);
+    load_tile_o(sDO, p.dout, p, pr, qb, tid);
+    if (tid < 64) {
+      const int r = qb + tid;
+      float mm = 0.f, lg = 0.f, dl = 0.f;
+      if (r < p.R) {
+        const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
+        mm = p.stats[si * 2]; lg = p.stats[si * 2 + 1]; dl = p.ws0[si];
+      }
+      sM[tid] = mm; sLg[tid] = lg; sDl[tid] = dl;
+    }
+    __syncthreads();
+
+    f32x4 pp[4], ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        s = mma16(frag_rows(sQ, t, kk, lane), kf[kk], s);
+        dp = mma16(frag_rows(sDO, t, kk, lane), vf[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = t * 16 + 4 * g + r, rqq = qb + ql;
+        float pv = 0.f;
+        if (kvalid && rqq < p.R && allowed(p, pr.n, rqq, rk)) {
+          const float sv = kpad ? F32_MIN : s[r];
+          pv = __expf((sv - sM[ql]) - sLg[ql]);
+        }
+        pp[t][r] = pv;
+        ds[t][r] = pv * (dp[r] - sDl[ql]);
+      }
+    }
+    const bf16x8 pf0 = pack_p(pp[0], pp[1]), pf1 = pack_p(pp[2], pp[3]);
+    const bf16x8 sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dv[dt] = mma16(frag_cols(sDO, dt, 0, lane), pf0, dv[dt]);
+      dv[dt] = mma16(frag_cols(sDO, dt, 1, lane), pf1, dv[dt]);
+      dk[dt] = mma16(frag_cols(sQ, dt, 0, lane), sf0, dk[dt]);
+      dk[dt] = mma16(frag_cols(sQ, dt, 1, lane), sf1, dk[dt]);
+    }
+    __syncthreads();
+  }
+  if (!kvalid) return;
+  if (p.mode == XP_ATTN_PROXY && rk < p.M) {
+    float* part = p.ws2 + ((int64_t)blockIdx.y * p.M + rk) * (2 * DH);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, dk[dt]); store4(part + DH + dt * 16 + 4 * g, dv[dt]); }
+    return;
+  }
+  bf16_t* base = p.dqkv + ktok * p.ldqkv + pr.h * DH;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, dk[dt]);
+    store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, dv[dt]);
+  }
+}
+
+// dQ: workgroup = 64 query rows; loops over key tiles (transposed orientation, per-lane query scalars).
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
+  char* sK = smem; char* sV = smem + TILE; unsigned char* sPad = reinterpret_cast<unsigned char*>(smem + 2 * TILE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+  const Prob pr(p, blockIdx.y);
+  const int qb = blockIdx.x * TQ;
+  const int rq = qb + wave * 16 + i16;
+  const bool qvalid = rq < p.R;
+  const int64_t qtok = (int64_t)pr.b * p.S + tok_of(p, pr.n, qvalid ? rq : 0);
+
+  bf16x8 qf[2], dof[2];
+  load_row_frag(qf, p.qkv + qtok * p.ldqkv + pr.h * DH, qvalid, g);
+  load_row_frag(dof, p.dout + qtok * p.ldo + pr.h * DH, qvalid, g);
+  float mq = 0.f, lgq = 0.f, dlq = 0.f;
+  if (qvalid) {
+    const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, rq);
+    mq = p.stats[si * 2]; lgq = p.stats[si * 2 + 1]; dlq = p.ws0[si];
+  }
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
+
+  int ntiles = (p.R + 63) / 64;
+  if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kb = kt * 64;
+    load_tile_qkv(sK, p, pr, 1, kb, tid);
+    load_tile_qkv(sV, p, pr, 2, kb, tid);
+    if (tid < 64) {
+      const int r = kb + tid;
+      sPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
+    }
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        s = mma16(frag_rows(sK, t, kk, lane), qf[kk], s);
+        dp = mma16(frag_rows(sV, t, kk, lane), dof[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kl = t * 16 + 4 * g + r, rk = kb + kl;
+        float pv = 0.f;
+        if (qvalid && rk < p.R && allowed(p, pr.n, rq, rk)) {
+          const float sv = sPad[kl] ? F32_MIN : s[r];
+          pv = __expf((sv - mq) - lgq);
+        }
+        ds[t][r] = pv * (dp[r] - dlq);
+      }
+    }
+    const bf16x8 sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dq[dt] = mma16(frag_cols(sK, dt, 0, lane), sf0, dq[dt]);
+      dq[dt] = mma16(frag_cols(sK, dt, 1, lane), sf1, dq[dt]);
+    }
+    __syncthreads();
+  }
+  if (!qvalid) return;
+  if (p.mode == XP_ATTN_PROXY && rq < p.M) {
+    float* part = p.ws1 + ((int64_t)blockIdx.y * p.M + rq) * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(part + dt * 16 + 4 * g, dq[dt]);
+    return;
+  }
+  bf16_t* base = p.dqkv + qtok * p.ldqkv + pr.h * DH;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) store4(base + dt * 16 + 4 * g, dq[dt] * p.q_scale);
+}
+
+// proxy tokens: sum the per-frame partials.  grid = B*H*M, 64 lanes = d
+__global__ void attn_bwd_proxy_reduce_kernel(AP p) {
+  const int d = threadIdx.x;
+  const int mrow = blockIdx.x % p.M, bh = blockIdx.x / p.M, h = bh % p.H, b = bh / p.H;
+  float q = 0.f, k = 0.f, v = 0.f;
+  for (int n = 0; n < p.N; ++n) {
+    const int64_t pi = ((int64_t)bh * p.N + n) * p.M + mrow;
+    q += p.ws1[pi * DH + d];
+    k += p.ws2[pi * 2 * DH + d];
+    v += p.ws2[pi * 2 * DH + DH + d];
+  }
+  bf16_t* base = p.dqkv + ((int64_t)b * p.S + mrow) * p.ldqkv + h * DH + d;
+  base[0] = (bf16_t)(q * p.q_scale);
+  base[(int64_t)p.H * DH] = (bf16_t)k;
+  base[(int64_t)2 * p.H * DH] = (bf16_t)v;
+}
+
+int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L,
+                 int64_t ldqkv, int64_t ldo, int32_t dtype) {
+  XP_REQUIRE(dtype == XP_BF16, "%s: only XP_BF16 is implemented for attention (got dtype %d)", name, dtype);
+  XP_REQUIRE(mode == XP_ATTN_PROXY || mode == XP_ATTN_CAUSAL, "%s: bad mode %d", name, mode);
+  XP_REQUIRE(B > 0 && H > 0 && S > 0, "%s: empty problem", name);
+  if (mode == XP_ATTN_PROXY) XP_REQUIRE(M >= 1 && N >= 1 && L >= 1 && S == M + N * L, "%s: S=%lld != M+N*L (%lld,%lld,%lld)",
+                                        name, (long long)S, (long long)M, (long long)N, (long long)L);
+  XP_REQUIRE(ldqkv >= 3 * H * DH && ldqkv % 8 == 0 && ldo >= H * DH && ldo % 8 == 0, "%s: bad leading dimensions", name);
+  XP_REQUIRE(B * H * (mode == XP_ATTN_PROXY ? N : 1) <= 65535 * 32, "%s: too many problems", name);
+  return XP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t xp_attn_workspace_bytes(int32_t mode, int64_t B, int64_t H, int64_t M, int64_t N, int64_t L) {
+  // S is M + N*L for PROXY; for CAUSAL callers pass M=0, N=1, L=S
+  const int64_t S = M + N * L;
+  const int64_t delta = B * H * S;
+  if (mode != XP_ATTN_PROXY) return (size_t)delta * sizeof(float);
+  const int64_t P = B * H * N;
+  const int64_t fwd = P * M * PART, bwd = delta + P * M * DH + P * M * 2 * DH;
+  return (size_t)(fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* stats,
+                           const int64_t* pad_mask, int32_t mode, int64_t B, int64_t H, int64_t S,
+                           int64_t M, int64_t N, int64_t L, int32_t dtype,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  XP_REQUIRE(qkv && out && stats, "xp_attn_fwd: null pointer");
+  if (mode == XP_ATTN_CAUSAL) { M = 0; N = 1; L = S; }
+  int rc = check_common("xp_attn_fwd", mode, B, H, S, M, N, L, ldqkv, ldo, dtype);
+  if (rc) return rc;
+  XP_REQUIRE(mode == XP_ATTN_CAUSAL || (workspace && workspace_bytes >= xp_attn_workspace_bytes(mode, B, H, M, N, L)),
+             "xp_attn_fwd: workspace too small");
+  AP p{};
+  p.qkv = (const bf16_t*)qkv; p.ldqkv = ldqkv; p.out = (bf16_t*)out; p.ldo = ldo; p.stats = stats; p.pad = pad_mask;
+  p.mode = mode; p.B = (int)B; p.H = (int)H; p.S = (int)S; p.M = (int)M; p.N = (int)N; p.L = (int)L;
+  p.R = mode == XP_ATTN_PROXY ? (int)(M + L) : (int)S;
+  p.ws0 = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(p.R, TQ), (unsigned)(B * H * N));
+  attn_fwd_kernel<<<grid, 256, 0, st>>>(p);
+  XP_CHECK_LAUNCH("xp_attn_fwd");
+  if (mode == XP_ATTN_PROXY) {
+    attn_fwd_merge_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
+    XP_CHECK_LAUNCH("xp_attn_fwd(merge)");
+  }
+  return XP_OK;
+}
+
+extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
+                           const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
+                           int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  XP_REQUIRE(qkv && out && dout && stats && dqkv, "xp_attn_bwd: null pointer");
+  if (mode == XP_ATTN_CAUSAL) { M = 0; N = 1; L = S; }
+  int rc = check_common("xp_attn_bwd", mode, B, H, S, M, N, L, ldqkv, ldo, dtype);
+  if (rc) return rc;
+  XP_REQUIRE(workspace && workspace_bytes >= xp_attn_workspace_bytes(mode, B, H, M, N, L), "xp_attn_bwd: workspace too small");
+  AP p{};
+  p.qkv = (const bf16_t*)qkv; p.ldqkv = ldqkv; p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.ldo = ldo;
+  p.dqkv = (bf16_t*)dqkv; p.stats = const_cast<float*>(stats); p.pad = pad_mask; p.q_scale = q_scale;
+  p.mode = mode; p.B = (int)B; p.H = (int)H; p.S = (int)S; p.M = (int)M; p.N = (int)N; p.L = (int)L;
+  p.R = mode == XP_ATTN_PROXY ? (int)(M + L) : (int)S;
+  const int64_t P = B * H * N;
+  p.ws0 = (float*)workspace; p.ws1 = p.ws0 + B * H * S; p.ws2 = p.ws1 + P * M * DH;
+  hipStream_t st = (hipStream_t)stream;
+  attn_delta_kernel<<<(unsigned)cdiv(B * S * H, 256), 256, 0, st>>>(p);
+  XP_CHECK_LAUNCH("xp_attn_bwd(delta)");
+  dim3 grid((unsigned)cdiv(p.R, TQ), (unsigned)P);
+  attn_bwd_dkv_kernel<<<grid, 256, 0, st>>>(p);
+  XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
+  attn_bwd_dq_kernel<<<grid, 256, 0, st>>>(p);
+  XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
+  if (mode == XP_ATTN_PROXY) {
+    attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
+    XP_CHECK_LAUNCH("xp_attn_bwd(proxy reduce)");
+  }
+  return XP_OK;
 }

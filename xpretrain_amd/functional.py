@@ -1,0 +1,313 @@
+"""Autograd layer over the HIP kernels: one ``torch.autograd.Function`` per *fused block* of the path.
+
+The unit of fusion is the transformer layer (``EncoderLayerFn``), not the op: the forward chains
+LN -> fused-QKV GEMM (+bias, q-scale) -> fused attention -> out-proj GEMM (+bias +residual) -> LN ->
+fc1 GEMM (+bias +quick_gelu) -> fc2 GEMM (+bias +residual); the backward chains the matching dX / dW
+GEMMs with the activation-derivative and residual-gradient adds folded into GEMM / LayerNorm epilogues.
+All arithmetic happens in ``libxpretrain_hip.so`` (``hip_ops``); torch only owns the buffers and the graph.
+
+Activations are 2-D ``[tokens, features]`` tensors in the compute dtype (bf16 by default); parameters stay
+fp32 masters and are cast once per weight version (``WeightCache``).  Parameter gradients are fp32.
+Reference call sites are cited per class (paths relative to /root/reference/CLIP-ViP/src).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import hip_ops as H
+
+
+# ------------------------------------------------------------------------------------------ weights
+class WeightCache:
+    """Compute-dtype copies of fp32 master weights, refreshed when the parameter's version counter moves
+    (optimizer steps / load_state_dict bump ``Tensor._version``)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w: torch.Tensor, dtype) -> torch.Tensor:
+        if dtype == torch.float32:
+            return w.detach()
+        key = (id(w), dtype)
+        ent = self._c.get(key)
+        ver = (w._version, w.data_ptr())
+        if ent is None or ent[0] != ver:
+            buf = ent[1] if ent is not None and ent[1].shape == w.shape else None
+            ent = (ver, H.cast(w.detach(), dtype, out=buf))
+            self._c[key] = ent
+        return ent[1]
+
+    def fused(self, ws, dtype) -> torch.Tensor:
+        """Row-concatenation of several [n_i, k] weights (or 1-D biases) in `dtype`: the fused QKV operand."""
+        key = (tuple(id(w) for w in ws), dtype)
+        ver = tuple((w._version, w.data_ptr()) for w in ws)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != ver:
+            rows = sum(w.shape[0] for w in ws)
+            buf = ent[1] if ent is not None else torch.empty((rows,) + tuple(ws[0].shape[1:]), dtype=dtype,
+                                                              device=ws[0].device)
+            r = 0
+            for w in ws:
+                H.cast(w.detach(), dtype, out=buf[r:r + w.shape[0]])
+                r += w.shape[0]
+            ent = (ver, buf)
+            self._c[key] = ent
+        return ent[1]
+
+    def clear(self):
+        self._c.clear()
+
+
+WEIGHTS = WeightCache()
+
+
+def _split_for(tiles: int, k: int) -> int:
+    """split-K factor for the weight-gradient GEMMs: fill ~one resident wave of workgroups (256 CUs x 2)."""
+    if tiles >= 256:
+        return 1
+    return max(1, min(512 // tiles, k // 512))
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, a_remap=(0, 0, 0)) -> torch.Tensor:
+    """dW[n_out, n_in] = dY[rows, n_out]^T . X[rows, n_in] in fp32 (both operands read k-strided, split-K)."""
+    tiles = ((n_out + 127) // 128) * ((n_in + 127) // 128)
+    split = _split_for(tiles, rows)
+    dw = torch.empty((n_out, n_in), dtype=torch.float32, device=dy.device)
+    if split == 1:
+        H.gemm(dy, x, n_out, n_in, rows, a_kstrided=True, b_kstrided=True, lda=n_out, ldb=n_in, out=dw,
+               out_dtype=torch.float32, a_remap=a_remap)
+    else:
+        ws = H.workspace(split * n_out * n_in * 4, dy.device, "splitk")
+        H.gemm(dy, x, n_out, n_in, rows, a_kstrided=True, b_kstrided=True, lda=n_out, ldb=n_in, out=ws,
+               split_k=split, a_remap=a_remap)
+        H.splitk_reduce(ws, dw)
+    return dw
+
+
+# ------------------------------------------------------------------------------------------ encoder layer
+class EncoderLayerFn(torch.autograd.Function):
+    """CLIPEncoderLayer.forward (modeling/CLIP_ViP.py:444-460) with CLIPAttention.forward2 (:332-381, video
+    tower, ``size=(M,N,L)``) or CLIPAttention.forward (:266-330, text tower, causal + padding) and CLIPMLP
+    (:392-396)."""
+
+    @staticmethod
+    def forward(ctx, x, ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2,
+                B: int, S: int, heads: int, size: Optional[Tuple[int, int, int]], pad_mask: Optional[torch.Tensor]):
+        dt = x.dtype
+        rows, D = x.shape
+        Dff = w1.shape[0]
+        dh = D // heads
+        if dh != 64:
+            raise RuntimeError(f"xpretrain_amd attention kernels are built for head_dim 64, got {dh}")
+        q_scale = dh ** -0.5
+        Wqkv = WEIGHTS.fused((wq, wk, wv), dt)
+        bqkv = WEIGHTS.fused((bq, bk, bv), torch.float32)
+        Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
+
+        h1, mean1, rstd1 = H.layernorm_fwd(x, ln1_w, ln1_b, rows, D)
+        qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D)
+        attn_o, stats = H.attn_fwd(qkv, B, S, heads, size=size, pad_mask=pad_mask)
+        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x)
+        h2, mean2, rstd2 = H.layernorm_fwd(x2, ln2_w, ln2_b, rows, D)
+        pre = torch.empty((rows, Dff), dtype=dt, device=x.device)
+        act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre)
+        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2)
+
+        ctx.save_for_backward(x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
+                              Wqkv, Wo, W1, W2, pad_mask)
+        ctx.meta = (B, S, heads, size, q_scale, D, Dff)
+        return x3
+
+    @staticmethod
+    def backward(ctx, dx3):
+        (x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
+         Wqkv, Wo, W1, W2, pad_mask) = ctx.saved_tensors
+        B, S, heads, size, q_scale, D, Dff = ctx.meta
+        rows = x.shape[0]
+        dx3 = dx3.contiguous()
+        # ---- MLP: x3 = x2 + fc2(quick_gelu(fc1(LN2(x2))))
+        dpre = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre)
+        dw2 = _wgrad(dx3, act, rows, D, Dff)
+        db2 = H.colsum(dx3, rows, D)
+        dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
+        dw1 = _wgrad(dpre, h2, rows, Dff, D)
+        db1 = H.colsum(dpre, rows, Dff)
+        dx2, dln2_w, dln2_b = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3)
+        # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
+        dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
+        dwo = _wgrad(dx2, attn_o, rows, D, D)
+        dbo = H.colsum(dx2, rows, D)
+        dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
+        dh1 = H.gemm(dqkv, Wqkv, rows, D, 3 * D, b_kstrided=True)
+        dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)
+        dbqkv = H.colsum(dqkv, rows, 3 * D)
+        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2)
+        dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
+        dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
+        return (dx, dln1_w, dln1_b, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dln2_w, dln2_b, dw1, db1, dw2, db2,
+                None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------ embeddings
+class VisionEmbedFn(torch.autograd.Function):
+    """CLIPVisionViPEmbeddings.forward (modeling/CLIP_ViP.py:168-197): conv patch embed as im2col + MFMA GEMM
+    whose epilogue adds temporal[t] + position[1+l] and writes straight into token slot M + t*L + l; proxy rows
+    (class_embedding / added_cls + position[0]) by a small fill kernel.  ``time_table`` is the [T,D] temporal
+    table (already interpolated by the caller when T != temporal_size, :171-174)."""
+
+    @staticmethod
+    def forward(ctx, video, patch_w, class_emb, added_cls, pos_w, time_table, dtype):
+        Bv, T, Cc, Hh, Ww = video.shape
+        D, _, P, _ = patch_w.shape
+        gh, gw = Hh // P, Ww // P
+        Lp = gh * gw
+        M = 1 + added_cls.shape[0]
+        S = M + T * Lp
+        if pos_w.shape[0] != 1 + Lp:
+            raise ValueError(f"position_embedding has {pos_w.shape[0]} rows but the frame has {Lp} patches (+1)")
+        K = 3 * P * P
+        patches = H.im2col(video.reshape(Bv * T, Cc, Hh, Ww).contiguous().float(), P, dtype)
+        Wp = WEIGHTS.get(patch_w, dtype).view(D, K)
+        x = torch.empty((Bv * S, D), dtype=dtype, device=video.device)
+        pos = pos_w.detach().contiguous()
+        tt = time_table.detach().contiguous().float()
+        H.gemm(patches, Wp, Bv * T * Lp, D, K, out=x, epilogue=L.EPI_PATCH, tab1=tt, tab2=pos[1:], tab_L=Lp,
+               c_remap=(T * Lp, S, M))
+        H.vip_proxy_rows(class_emb.detach(), added_cls.detach().contiguous(), pos, x, Bv, S, M, D)
+        ctx.save_for_backward(patches)
+        ctx.meta = (Bv, T, Lp, M, S, D, K, tuple(patch_w.shape), added_cls.shape[0])
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (patches,) = ctx.saved_tensors
+        Bv, T, Lp, M, S, D, K, wshape, nadd = ctx.meta
+        dx = dx.contiguous()
+        d_class, d_added, d_pos, d_time = H.vip_embed_bwd(dx, Bv, M, T, Lp, D)
+        dwp = _wgrad(dx, patches, Bv * T * Lp, D, K, a_remap=(T * Lp, S, M)).view(wshape)
+        return None, dwp, d_class, d_added[:nadd], d_pos, d_time, None
+
+
+class TextEmbedFn(torch.autograd.Function):
+    """CLIPTextEmbeddings.forward (modeling/CLIP_ViP.py:210-227): token_embedding[ids] + position_embedding[:Lt]."""
+
+    @staticmethod
+    def forward(ctx, ids, tok_w, pos_w, dtype):
+        ids = ids.contiguous()
+        x = H.text_embed_fwd(ids, tok_w.detach(), pos_w.detach(), dtype)
+        ctx.save_for_backward(ids)
+        ctx.meta = (tok_w.shape[0], pos_w.shape[0])
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids,) = ctx.saved_tensors
+        d_tok, d_pos = H.text_embed_bwd(ids, dx.contiguous(), *ctx.meta)
+        return None, d_tok, d_pos, None
+
+
+# ------------------------------------------------------------------------------------------ small blocks
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm (pre_layrnorm :881, post_layernorm :893, final_layer_norm :772)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        rows, D = x.shape
+        y, mean, rstd = H.layernorm_fwd(x, gamma.detach(), beta.detach(), rows, D)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        rows, D = x.shape
+        dx, dg, db = H.layernorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd, rows, D)
+        return dx, dg, db
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """pooled[b] = x[b, idx[b]]  (EOT-argmax pooling :776; idx=None -> token 0, the class proxy, :892)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, B, S):
+        D = x.shape[1]
+        ctx.save_for_backward(idx)
+        ctx.meta = (B, S, D)
+        return H.gather_rows(x, idx, B, S, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, S, D = ctx.meta
+        return H.scatter_rows(dout.contiguous(), idx, B, S, D), None, None, None
+
+
+class ProjectionFn(torch.autograd.Function):
+    """bias-free nn.Linear: visual_projection / text_projection (:1142,:1145)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        rows, K = x.shape
+        N = w.shape[0]
+        Wc = WEIGHTS.get(w, x.dtype)
+        ctx.save_for_backward(x, Wc)
+        return H.gemm(x, Wc, rows, N, K)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wc = ctx.saved_tensors
+        rows, K = x.shape
+        N = Wc.shape[0]
+        dy = dy.contiguous()
+        dx = H.gemm(dy, Wc, rows, K, N, b_kstrided=True)
+        dw = _wgrad(dy, x, rows, N, K)
+        return dx, dw
+
+
+class L2NormFn(torch.autograd.Function):
+    """x / ||x||_2 (:1148-1149); fp32 unit-norm features out."""
+
+    @staticmethod
+    def forward(ctx, x):
+        rows, D = x.shape
+        y, inv = H.l2norm_fwd(x, rows, D)
+        ctx.save_for_backward(y, inv)
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        rows, D = y.shape
+        return H.l2norm_bwd(dy.contiguous().float(), y, inv, rows, D, ctx.dtype)
+
+
+class NCELossFn(torch.autograd.Function):
+    """NCELearnableTempLoss.forward (optimization/loss.py:134-141).  The kernel produces the loss and its
+    gradients in one pass; backward only applies the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, vis, txt, log_scale):
+        loss, dv, dt, dls = H.nce_loss(vis.contiguous().float(), txt.contiguous().float(),
+                                       log_scale.detach().float().reshape(()))
+        ctx.save_for_backward(dv, dt, dls)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, dt, dls = ctx.saved_tensors
+        return dv * g, dt * g, dls * g
+
+
+def encoder_layer(x, layer, B, S, heads, size, pad_mask):
+    """Apply ``EncoderLayerFn`` with the parameters of a ``CLIPEncoderLayer`` module."""
+    a, m = layer.self_attn, layer.mlp
+    return EncoderLayerFn.apply(
+        x, layer.layer_norm1.weight, layer.layer_norm1.bias,
+        a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight, a.v_proj.bias,
+        a.out_proj.weight, a.out_proj.bias, layer.layer_norm2.weight, layer.layer_norm2.bias,
+        m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, B, S, heads, size, pad_mask)

@@ -264,3 +264,36 @@ def nce_loss(vis: torch.Tensor, txt: torch.Tensor, log_scale: torch.Tensor):
     L.check(L.lib().xp_nce_loss(_p(vis), _p(txt), _p(log_scale), _p(loss), _p(dv), _p(dt), _p(dls), n, d, _p(ws),
                                 ws.numel(), _stream()), "xp_nce_loss")
     return loss, dv, dt, dls
+
+
+# --------------------------------------------------------------------------------------- attention
+def _attn_ws(mode, B, H, M, N, Lp, device):
+    nb = L.lib().xp_attn_workspace_bytes(mode, B, H, M, N, Lp)
+    return workspace(nb, device, "attn")
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, *, size=None, pad_mask=None):
+    """qkv [B*S, 3*H*64] (q pre-scaled).  size=(M,N,L) selects the video-proxy pattern, otherwise the
+    causal(+padding) text pattern.  Returns (out [B*S, H*64], stats [B,H,S,2])."""
+    _chk(qkv, "qkv")
+    mode = L.ATTN_PROXY if size is not None else L.ATTN_CAUSAL
+    M, N, Lp = size if size is not None else (0, 1, S)
+    out = torch.empty((B * S, H * 64), dtype=qkv.dtype, device=qkv.device)
+    stats = torch.empty((B, H, S, 2), dtype=torch.float32, device=qkv.device)
+    if pad_mask is not None:
+        _chk(pad_mask, "pad_mask", torch.int64)
+    ws = _attn_ws(mode, B, H, M, N, Lp, qkv.device)
+    L.check(L.lib().xp_attn_fwd(_p(qkv), 3 * H * 64, _p(out), H * 64, _p(stats), _p(pad_mask), mode, B, H, S, M, N, Lp,
+                                _dt(qkv), _p(ws), ws.numel(), _stream()), "xp_attn_fwd")
+    return out, stats
+
+
+def attn_bwd(qkv, out, dout, stats, B, S, H, *, size=None, pad_mask=None, q_scale=1.0):
+    mode = L.ATTN_PROXY if size is not None else L.ATTN_CAUSAL
+    M, N, Lp = size if size is not None else (0, 1, S)
+    dqkv = torch.empty_like(qkv)
+    ws = _attn_ws(mode, B, H, M, N, Lp, qkv.device)
+    L.check(L.lib().xp_attn_bwd(_p(qkv), 3 * H * 64, _p(out), _p(dout), H * 64, _p(stats), _p(pad_mask), _p(dqkv),
+                                float(q_scale), mode, B, H, S, M, N, Lp, _dt(qkv), _p(ws), ws.numel(), _stream()),
+            "xp_attn_bwd")
+    return dqkv
