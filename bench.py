@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Headline benchmark: CLIP-ViP video-text contrastive training step on MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+One "step" = clamp logit_scale -> VidCLIP.forward (ViT-B/16 video tower with video-proxy tokens + CLIP text
+tower) -> packed all-gather of features (N>1) -> NCELearnableTempLoss -> backward -> bucketed gradient
+all-reduce overlapped with backward -> global-norm clip 5.0 -> AdamW step, on BASELINE config #2 per GPU:
+B=8 pairs, T=12 frames 224x224, 32 text tokens, bf16 compute / fp32 master weights, synthetic inputs resident
+in HBM, random-init weights of the named architecture.  Weak scaling: per-GPU batch fixed.
+
+Prints ONE JSON line on rank 0 (metric/value/..., plus `roofline` for the dominant kernel and `cpu_baseline`).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE cfg #2: 8)")
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--patch", type=int, default=16)
+    ap.add_argument("--txt-len", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+class Args:
+    def __init__(self, cfg):
+        self.clip_config = cfg
+        self.clip_weights = ""
+        self.clip_vision_additional_config = dict(type="ViP", temporal_size=12, if_use_temporal_embed=1,
+                                                  logit_scale_init_value=4.6, add_cls_num=3)
+
+
+def time_dominant_kernel(dev, rows, D=768, Dff=3072, iters=30):
+    """fc1 forward GEMM (+bias +quick_gelu epilogue): the largest single kernel of the step (26% of forward FLOPs).
+    Timed with HIP events on the stream the kernel is launched on (torch's current stream)."""
+    from xpretrain_amd import hip_ops as H, _lib as L
+    bf = torch.bfloat16
+    A = torch.randn(rows, D, device=dev).to(bf)
+    W = (torch.randn(Dff, D, device=dev) * 0.02).to(bf)
+    bias = torch.zeros(Dff, device=dev)
+    out = torch.empty(rows, Dff, dtype=bf, device=dev)
+    aux = torch.empty(rows, Dff, dtype=bf, device=dev)
+    f = lambda: H.gemm(A, W, rows, Dff, D, out=out, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flops = 2.0 * rows * D * Dff
+    return flops / (ms * 1e-3) / 1e12, ms
+
+
+def cpu_baseline(args):
+    """The CPU oracle (port of the reference algorithm, oracle/clipvip_oracle.py) on this host's cores:
+    one fwd+loss+bwd step at a reduced batch of the same config (bounded to ~10-30 s)."""
+    from oracle import clipvip_oracle as O
+    torch.manual_seed(1234)
+    from xpretrain_amd.modeling import VidCLIP
+    cfgd = O.vit_b_config(args.patch, args.res)
+    model = VidCLIP(Args(cfgd))
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
+    del model
+    Bc = args.cpu_baseline_batch
+    video, ids, mask = O.synthetic_inputs(Bc, args.frames, args.res, args.txt_len)
+    cfg = O.OracleCfg.from_hf_dict(cfgd)
+    t0 = time.time()
+    loss, _, _ = O.full_step(video, ids, mask, sd, cfg)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": round(Bc / dt, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/clipvip_oracle.py fp32, 1 step fwd+loss+bwd (no optimizer), B={Bc} of the same "
+                      f"T={args.frames}/{args.res}^2/Lt={args.txt_len} ViT-B/{args.patch} config, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    from xpretrain_amd import distributed as D
+    local_rank = D.init_from_env()
+    W, rank = D.world_size(), D.rank()
+    assert W == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={W}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from oracle import clipvip_oracle as O          # input generator + FLOP model only (not on the timed path)
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+
+    torch.manual_seed(1234)
+    cfgd = O.vit_b_config(a.patch, a.res)
+    model = VidCLIP(Args(cfgd))
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.02)
+    model.to(dev).train()
+    D.broadcast_parameters(model)
+    loss_fn = NCELearnableTempLoss()
+    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True)
+    decay = [p for n, p in model.named_parameters() if p.dim() >= 2 and "logit_scale" not in n]
+    no_decay = [p for n, p in model.named_parameters() if not (p.dim() >= 2 and "logit_scale" not in n)]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}],
+                            lr=5e-6, betas=(0.9, 0.98), eps=1e-6, fused=True)
+    video, ids, mask = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank)
+    video, ids, mask = video.to(dev), ids.to(dev), mask.to(dev)
+    logit_scale = model.clipmodel.logit_scale
+    params = [p for p in model.parameters()]
+
+    def step():
+        with torch.no_grad():
+            logit_scale.clamp_(0, math.log(200.0))                       # run_pretrain.py:335-340
+        out = model(video, ids, mask)
+        vis, txt = D.gather_features(out["vis_features"], out["text_features"])
+        loss = loss_fn(vis, txt, logit_scale)
+        loss.backward()
+        reducer.synchronize()
+        torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)        # run_pretrain.py:408-411
+        opt.step()
+        reducer.zero_grad()
+        return loss
+
+    def sync():
+        if W > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if W > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    # ViT-forward-only time (north-star target: <= 3.4 ms at cfg #2), inference mode, weights cached
+    with torch.no_grad():
+        for _ in range(2):
+            model.clipmodel.vision_model(pixel_values=video)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            model.clipmodel.vision_model(pixel_values=video)
+        e.record()
+        torch.cuda.synchronize()
+        vit_fwd_ms = s.elapsed_time(e) / 5
+
+    if rank == 0:
+        f_vis, f_txt = O.flops_per_pair(a.frames, a.res, a.txt_len, a.patch)
+        pairs_s = W * a.batch * a.steps / dt
+        step_flops = 3.0 * (f_vis + f_txt) * a.batch                     # per GPU, fwd+bwd convention
+        rows = a.batch * (4 + a.frames * (a.res // a.patch) ** 2)
+        k_tf, k_ms = time_dominant_kernel(dev, rows)
+        res = {
+            "metric": "video-text pairs/sec", "value": round(pairs_s, 3), "unit": "pairs/s", "n_gpus": W,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"CLIP-ViP ViT-B/{a.patch} video-text contrastive train step (fwd+loss+bwd+grad-sync+"
+                                   f"clip+AdamW), {a.frames} frames {a.res}^2, {a.txt_len} text tokens, "
+                                   f"local batch {a.batch}, BASELINE configs[1]" + ("" if W == 1 else "/[2]"),
+                       "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4)},
+            "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
+            "step_frac_of_bf16_peak": round(step_flops / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "vit_forward_ms": round(vit_fwd_ms, 3),
+            "vit_forward_frac_of_bf16_peak": round(f_vis * a.batch / (vit_fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16,NT> fc1 +bias+quick_gelu "
+                                                    f"[{rows}x768]x[768x3072]",
+                         "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(k_ms, 4), "traffic": None},
+        }
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(res), flush=True)
+    if W > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

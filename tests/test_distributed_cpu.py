@@ -1,0 +1,72 @@
+"""CPU, gloo, world_size 2: the data-parallel glue (xpretrain_amd/distributed.py) reproduces the
+single-process result on the concatenated global batch (SURVEY.md §5 "DP parity target"):
+loss identical; feature-path gradients = global gradient / W (Horovod averaging); logit_scale gradient exact;
+the no-collective gather backward equals the all-reduce Horovod would run."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import clipvip_oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from xpretrain_amd import distributed as D
+    D.init_from_env("gloo")
+    torch.manual_seed(0)
+    B, d = 3, 16
+    # a tiny "encoder": features = normalize(x @ W); same weights on every rank, different data per rank
+    Wv = torch.nn.Parameter(torch.randn(8, d)); Wt = torch.nn.Parameter(torch.randn(8, d))
+    ls = torch.nn.Parameter(torch.tensor(2.0))
+    D.broadcast_parameters(torch.nn.ParameterList([Wv, Wt, ls]))
+    g = torch.Generator().manual_seed(100)
+    xv_all, xt_all = torch.randn(world * B, 8, generator=g), torch.randn(world * B, 8, generator=g)
+    xv, xt = xv_all[rank * B:(rank + 1) * B], xt_all[rank * B:(rank + 1) * B]
+    red = D.GradBucketReducer([Wv, Wt, ls], bucket_mb=0.0001, average=True)
+    assert len(red.buckets) >= 2
+    for step in range(2):                       # second step checks zero_grad / bucket reuse
+        red.zero_grad()
+        vis = torch.nn.functional.normalize(xv @ Wv, dim=-1); txt = torch.nn.functional.normalize(xt @ Wt, dim=-1)
+        gv, gt = D.gather_features(vis, txt, verify_identical=True)
+        loss = O.nce_learnable_temp_loss(gv, gt, ls)
+        loss.backward()
+        red.synchronize()
+    # single-process oracle on the global batch
+    Wv2, Wt2, ls2 = Wv.detach().clone().requires_grad_(), Wt.detach().clone().requires_grad_(), ls.detach().clone().requires_grad_()
+    ref = O.nce_learnable_temp_loss(torch.nn.functional.normalize(xv_all @ Wv2, dim=-1),
+                                    torch.nn.functional.normalize(xt_all @ Wt2, dim=-1), ls2)
+    ref.backward()
+    ok = (torch.allclose(loss, ref, atol=1e-6)
+          and torch.allclose(Wv.grad, Wv2.grad / world, atol=1e-6) and torch.allclose(Wt.grad, Wt2.grad / world, atol=1e-6)
+          and torch.allclose(ls.grad, ls2.grad, atol=1e-6))
+    q.put((rank, bool(ok), float(loss), float(ref)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world2_matches_global_batch_oracle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def test_single_process_passthrough():
+    from xpretrain_amd import distributed as D
+    a, b = torch.randn(2, 4), torch.randn(2, 4)
+    ga, gb = D.gather_features(a, b)
+    assert ga is a and gb is b and D.world_size() == 1 and D.rank() == 0

@@ -1,0 +1,108 @@
+"""GPU: end-to-end parity of the HIP path (VidCLIP.forward -> NCELearnableTempLoss -> backward) against
+(1) the reference-generated fixture tests/golden/tiny_e2e.pt (fp32 outputs of the UNMODIFIED reference) and
+(2) the CPU oracle at BASELINE cfg #1's architecture (ViT-B/32, T=2, Lt=16), bf16 tolerance 2e-2 as
+BASELINE.json:north_star states (on unit-norm features / loss / max-norm-relative gradients)."""
+import pytest
+import torch
+
+from oracle import clipvip_oracle as O
+from tests.gpu_util import report
+
+pytestmark = pytest.mark.gpu
+
+
+class _Args:
+    def __init__(self, cfg, temporal_size, add_cls_num=3):
+        self.clip_config = cfg
+        self.clip_weights = ""
+        self.clip_vision_additional_config = dict(type="ViP", temporal_size=temporal_size, if_use_temporal_embed=1,
+                                                  logit_scale_init_value=4.6, add_cls_num=add_cls_num)
+
+
+def test_tiny_e2e_against_reference_fixture(golden):
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    fx = golden("tiny_e2e.pt")
+    model = VidCLIP(_Args(fx["config"], fx["temporal_size"], fx["add_cls_num"]))
+    model.load_state_dict(fx["state_dict"], strict=True)
+    model.cuda().train()
+    vo = model.clipmodel.vision_model(pixel_values=fx["video"].cuda(), output_hidden_states=True)
+    for i, (a, b) in enumerate(zip(vo["hidden_states"], fx["vision_hidden"])):
+        assert report(f"tiny vision hidden[{i}]", a, b, 2e-2) <= 2e-2
+    assert report("tiny vision pooled", vo["pooler_output"], fx["vision_pooled"], 2e-2) <= 2e-2
+    to = model.clipmodel.text_model(input_ids=fx["ids"].cuda(), attention_mask=fx["mask"].cuda(), output_hidden_states=True)
+    for i, (a, b) in enumerate(zip(to["hidden_states"], fx["text_hidden"])):
+        assert report(f"tiny text hidden[{i}]", a, b, 2e-2) <= 2e-2
+    assert report("tiny text last", to["last_hidden_state"], fx["text_last"], 2e-2) <= 2e-2
+    assert report("tiny text pooled", to["pooler_output"], fx["text_pooled"], 2e-2) <= 2e-2
+
+    out = model(fx["video"].cuda(), fx["ids"].cuda(), fx["mask"].cuda())
+    assert (out["vis_features"].cpu() - fx["vis_features"]).abs().max() < 2e-2
+    assert (out["text_features"].cpu() - fx["text_features"]).abs().max() < 2e-2
+    loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+    assert abs(loss.item() - fx["loss"].item()) < 2e-2 * max(1.0, fx["loss"].item())
+    loss.backward()
+    bad = []
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        ref = fx["grads"][name]
+        e = report(f"tiny grad {name}", p.grad, ref, 6e-2) if ref.abs().max() > 1e-4 else 0.0
+        if e > 6e-2:
+            bad.append((name, e))
+    assert not bad, bad
+
+
+def test_cfg1_architecture_against_oracle():
+    """BASELINE config #1: ViT-B/32, 2 frames 224^2, 16 text tokens, batch 2."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    torch.manual_seed(1234)
+    cfgd = O.vit_b_config(patch=32)
+    model = VidCLIP(_Args(cfgd, 12))
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.02)
+    video, ids, mask = O.synthetic_inputs(2, 2, 224, 16)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
+    ref_loss, ref_vis, ref_txt = O.full_step(video, ids, mask, sd, O.OracleCfg.from_hf_dict(cfgd))
+    ref_loss.backward()
+    model.cuda().train()
+    out = model(video.cuda(), ids.cuda(), mask.cuda())
+    loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+    loss.backward()
+    dv = (out["vis_features"].cpu() - ref_vis).abs().max().item()
+    dt = (out["text_features"].cpu() - ref_txt).abs().max().item()
+    print(f"cfg1: loss {loss.item():.6f} oracle {ref_loss.item():.6f} dvis {dv:.2e} dtxt {dt:.2e}")
+    assert dv < 2e-2 and dt < 2e-2
+    assert abs(loss.item() - ref_loss.item()) < 2e-2
+    worst = 0.0
+    for name, p in model.named_parameters():
+        ref = sd[name[len("clipmodel."):]].grad
+        assert p.grad is not None and ref is not None, name
+        if ref.abs().max() > 1e-5:
+            worst = max(worst, report(f"cfg1 grad {name}", p.grad, ref, 8e-2))
+    assert worst <= 8e-2
+
+
+def test_second_pass_T1_interpolated_temporal_embedding():
+    """VidCLIP's image/caption pass runs the video tower at T=1 (VidCLIP.py:70-79): exercises the linear
+    interpolation of temporal_embedding 12 -> 1 and its gradient."""
+    from xpretrain_amd.modeling import VidCLIP
+    torch.manual_seed(7)
+    cfgd = O.hf_config_dict(128, 2, 1, 256, 16, 32, 128, 2, 1, 256, 120, 16, 64)
+    model = VidCLIP(_Args(cfgd, 12))
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.5)
+    video, ids, mask = O.synthetic_inputs(3, 2, 32, 8, vocab=120)
+    image = video[:, :1].contiguous()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
+    cfg = O.OracleCfg.from_hf_dict(cfgd)
+    rv, _ = O.clip_features(image, ids, mask, sd, cfg)
+    rv.sum().backward()
+    model.cuda()
+    out = model(video.cuda(), ids.cuda(), mask.cuda(), image=image.cuda(), caption_ids=ids[:, None].cuda(),
+                caption_masks=mask[:, None].cuda())
+    assert (out["img_features"].cpu() - rv).abs().max() < 2e-2
+    out["img_features"].sum().backward()
+    g = model.clipmodel.vision_model.embeddings.temporal_embedding.grad.cpu()
+    gr = sd["vision_model.embeddings.temporal_embedding"].grad
+    assert report("temporal_embedding grad (T=1 interp)", g, gr, 6e-2) <= 6e-2

@@ -1,0 +1,173 @@
+"""Data-parallel glue for one 8xMI355X node: one process per GPU, ``torch.distributed`` backend ``nccl``
+(= RCCL over xGMI on ROCm).  Replaces the reference's Horovod usage (run_pretrain.py:226-232,344-353,379;
+utils/distributed.py) with three pieces designed for point-to-point xGMI rather than NVSwitch:
+
+* ``gather_features``  -- ONE packed all-gather of the [2,B,d] (video,text) features per step instead of two
+  (16 KB messages are latency-bound), differentiable.  Backward takes the LOCAL slice of the
+  incoming gradient and issues no collective: every rank computes the same loss from bit-identical gathered
+  inputs, so Horovod's averaged all-reduce in allgather-backward is a numerical no-op (SURVEY.md §5/§8e;
+  ``verify_identical=True`` runs the real all-reduce and asserts that).
+* ``GradBucketReducer`` -- parameters' ``.grad`` are views into a few large flat fp32 buckets (layer-reverse
+  order, ~64 MB each: few, big messages that keep all 7 xGMI links busy); a bucket's all-reduce is launched
+  asynchronously from the autograd hook of its last gradient, overlapping the rest of backward.
+  ``average=True`` reproduces ``hvd.DistributedOptimizer`` (grads / world_size).
+* ``broadcast_parameters`` -- rank-0 -> all at start-up (hvd.broadcast_parameters, run_pretrain.py:231).
+
+Everything is backend-agnostic (the CPU tests run it on ``gloo`` with world_size 2).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> int:
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns local rank."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend)
+    return local_rank
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """concat over ranks along dim 0 (rank order), differentiable -- ``hvd.allgather`` semantics."""
+
+    @staticmethod
+    def forward(ctx, x, verify_identical):
+        W = world_size()
+        ctx.verify = verify_identical
+        ctx.n = x.shape[0]
+        x = x.contiguous()
+        out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r = rank()
+        if ctx.verify:    # debug switch: the collective Horovod would run; must equal the local gradient
+            avg = g.clone()
+            dist.all_reduce(avg)
+            avg /= world_size()
+            if not torch.allclose(avg, g, rtol=1e-5, atol=1e-7):
+                raise RuntimeError("gathered-feature gradients differ across ranks: the no-collective backward "
+                                   "of gather_features is not valid for this loss")
+        return g[r * ctx.n:(r + 1) * ctx.n], None
+
+
+def allgather(x: torch.Tensor, verify_identical: bool = False) -> torch.Tensor:
+    if world_size() == 1:
+        return x
+    return _AllGatherRows.apply(x, verify_identical)
+
+
+def gather_features(vis: torch.Tensor, txt: torch.Tensor, verify_identical: bool = False):
+    """(vis[B,d], txt[B,d]) -> (vis[W*B,d], txt[W*B,d]) with ONE collective."""
+    if world_size() == 1:
+        return vis, txt
+    B = vis.shape[0]
+    packed = torch.stack([vis, txt], dim=1)                       # [B,2,d]: rows stay rank-major after the gather
+    g = _AllGatherRows.apply(packed, verify_identical)            # [W*B,2,d]
+    return g[:, 0], g[:, 1]
+
+
+class GradBucketReducer:
+    """Bucketed, backward-overlapped gradient all-reduce (the role of hvd.DistributedOptimizer + synchronize())."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, average: bool = True,
+                 group=None):
+        self.group = group
+        self.average = average
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.buckets = []
+        self._bucket_of = {}
+        cap = int(bucket_mb * (1 << 20)) // 4
+        cur, cur_n = [], 0
+        for p in reversed(self.params):        # gradients become ready roughly in reverse parameter order
+            if cur and cur_n + p.numel() > cap:
+                self._make_bucket(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._make_bucket(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _make_bucket(self, ps):
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        b = dict(flat=flat, params=list(ps), views={}, ready=0, work=None)
+        off = 0
+        for p in ps:
+            v = flat[off:off + p.numel()].view_as(p)
+            b["views"][id(p)] = v
+            p.grad = v
+            self._bucket_of[id(p)] = b
+            off += p.numel()
+        self.buckets.append(b)
+
+    def _launch(self, b):
+        if world_size() > 1:
+            b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        v = b["views"][id(p)]
+        if p.grad is not v:                    # someone replaced .grad (zero_grad(set_to_none=True)): re-home it
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+        b["ready"] += 1
+        if b["ready"] == len(b["params"]):
+            self._launch(b)
+
+    def synchronize(self):
+        """Wait for every bucket (launching those whose parameters got no gradient this step) and average."""
+        W = world_size()
+        for b in self.buckets:
+            if b["work"] is None and W > 1 and b["ready"] < len(b["params"]):
+                self._launch(b)
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+                b["work"] = None
+            if self.average and W > 1:
+                b["flat"].div_(W)
+            b["ready"] = 0
+
+    def zero_grad(self):
+        """Use instead of optimizer.zero_grad(): keeps ``.grad`` pointing into the flat buckets."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            for p in b["params"]:
+                p.grad = b["views"][id(p)]
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0):
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src)

@@ -1,0 +1,447 @@
+"""CLIP-ViP model surface on the MI355X HIP kernels -- drop-in for the reference's
+``src/modeling/CLIP_ViP.py`` (same class names, constructor arguments, parameter/buffer names and
+``state_dict`` keys -- ``pre_layrnorm`` typo included -- and the same forward keyword names).
+
+The ``nn.Linear`` / ``nn.LayerNorm`` / ``nn.Embedding`` / ``nn.Conv2d`` sub-modules are used purely as
+*parameter containers* so that checkpoints round-trip key-for-key; their ``forward`` is
+never called.  All arithmetic runs in ``libxpretrain_hip.so`` through ``xpretrain_amd.functional``.
+There is no CPU path: tensors must live on an MI355X.
+
+Deliberate differences from the reference (SURVEY.md §8a "known defects"):
+  * ``CLIPVisionModel(config, additional_vision_config)`` accepts the ViP config (the reference's
+    constructor drops it and raises AttributeError at CLIP_ViP.py:148).
+  * half precision is bf16 with fp32 softmax/LayerNorm statistics (the reference is fp16 under apex O2).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import functional as XF
+
+try:  # config classes only -- same import the reference uses (CLIP_ViP.py:36)
+    from transformers.models.clip.configuration_clip import CLIPConfig, CLIPTextConfig, CLIPVisionConfig
+except Exception:  # pragma: no cover - transformers is present in the image
+    CLIPConfig = CLIPTextConfig = CLIPVisionConfig = None
+
+
+class _Cfg(dict):
+    """attribute-style view of a plain dict (stands in for easydict / HF sub-configs)."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _as_cfg(c):
+    if c is None or hasattr(c, "hidden_size") or not isinstance(c, dict):
+        return c
+    return _Cfg(c)
+
+
+class CLIPOutput(dict):
+    """dict with attribute access: loss, logits_per_image, logits_per_text, text_embeds, image_embeds,
+    text_model_output, vision_model_output (reference CLIPOutput, CLIP_ViP.py:76-111)."""
+    __getattr__ = dict.get
+
+
+class BaseModelOutputWithPooling(dict):
+    __getattr__ = dict.get
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return (self["last_hidden_state"], self["pooler_output"])[k]
+        return dict.__getitem__(self, k)
+
+
+# ------------------------------------------------------------------------------------------ embeddings
+class CLIPVisionViPEmbeddings(nn.Module):
+    """reference: CLIP_ViP.py:142-197"""
+
+    def __init__(self, config, additional_vision_config=None):
+        super().__init__()
+        add = _as_cfg(additional_vision_config)
+        if add is None:
+            raise ValueError("CLIPVisionViPEmbeddings needs additional_vision_config "
+                             "(temporal_size, if_use_temporal_embed, add_cls_num)")
+        self.config = config
+        self.embed_dim = config.hidden_size
+        self.image_size = config.image_size
+        self.temporal_size = add.temporal_size
+        self.if_use_temporal_embed = add.if_use_temporal_embed
+        self.patch_size = config.patch_size
+        self.add_cls_num = add.add_cls_num
+        self.added_cls = nn.Parameter(torch.randn(self.add_cls_num, self.embed_dim))
+        self.class_embedding = nn.Parameter(torch.randn(self.embed_dim))
+        self.patch_embedding = nn.Conv2d(3, self.embed_dim, kernel_size=self.patch_size, stride=self.patch_size, bias=False)
+        self.num_patches = (self.image_size // self.patch_size) ** 2
+        self.num_positions = self.num_patches + 1
+        self.position_embedding = nn.Embedding(self.num_positions, self.embed_dim)
+        self.register_buffer("position_ids", torch.arange(self.num_positions).expand((1, -1)))
+        if self.if_use_temporal_embed:
+            self.temporal_embedding = nn.Parameter(torch.zeros(1, self.temporal_size, self.embed_dim))
+
+    def forward(self, pixel_values: torch.Tensor, dtype=torch.bfloat16):
+        B, T, C, H, W = pixel_values.shape
+        if self.if_use_temporal_embed:
+            te = self.temporal_embedding
+            if T != te.shape[1]:   # tiny [1,D,Tt] tensor: stays in torch so autograd reaches the parameter (:171-174)
+                te = F.interpolate(te.transpose(1, 2), size=T, mode="linear").transpose(1, 2)
+            time_table = te[0]
+        else:
+            time_table = torch.zeros(T, self.embed_dim, device=pixel_values.device)
+        x = XF.VisionEmbedFn.apply(pixel_values, self.patch_embedding.weight, self.class_embedding, self.added_cls,
+                                   self.position_embedding.weight, time_table, dtype)
+        M = 1 + self.add_cls_num
+        L = (H // self.patch_size) * (W // self.patch_size)
+        return x, (M, T, L)          # x: [B*(M+T*L), D]
+
+
+class CLIPTextEmbeddings(nn.Module):
+    """reference: CLIP_ViP.py:199-227"""
+
+    def __init__(self, config):
+        super().__init__()
+        embed_dim = config.hidden_size
+        self.token_embedding = nn.Embedding(config.vocab_size, embed_dim)
+        self.position_embedding = nn.Embedding(config.max_position_embeddings, embed_dim)
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+
+    def forward(self, input_ids, position_ids=None, dtype=torch.bfloat16):
+        if position_ids is not None:
+            raise NotImplementedError("custom position_ids are not on the CLIP-ViP path (run_pretrain.py never passes them)")
+        if input_ids.shape[-1] > self.position_embedding.weight.shape[0]:
+            raise ValueError("sequence longer than max_position_embeddings")
+        return XF.TextEmbedFn.apply(input_ids, self.token_embedding.weight, self.position_embedding.weight, dtype)
+
+
+# ------------------------------------------------------------------------------------------ blocks
+class CLIPAttention(nn.Module):
+    """parameter container for q/k/v/out projections (reference: CLIP_ViP.py:230-381)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embed_dim = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.embed_dim // self.num_heads
+        assert self.head_dim * self.num_heads == self.embed_dim
+        self.scale = self.head_dim ** -0.5
+        self.dropout = config.attention_dropout
+        if self.dropout:
+            raise NotImplementedError("attention_dropout > 0 is not on the CLIP-ViP path (all shipped configs use 0.0)")
+        self.k_proj = nn.Linear(self.embed_dim, self.embed_dim)
+        self.v_proj = nn.Linear(self.embed_dim, self.embed_dim)
+        self.q_proj = nn.Linear(self.embed_dim, self.embed_dim)
+        self.out_proj = nn.Linear(self.embed_dim, self.embed_dim)
+
+
+class CLIPMLP(nn.Module):
+    """reference: CLIP_ViP.py:384-396"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if config.hidden_act != "quick_gelu":
+            raise NotImplementedError(f"hidden_act={config.hidden_act!r}: the fused MLP epilogue implements quick_gelu "
+                                      "(every openai/clip-* config)")
+        self.fc1 = nn.Linear(config.hidden_size, config.intermediate_size)
+        self.fc2 = nn.Linear(config.intermediate_size, config.hidden_size)
+
+
+class CLIPEncoderLayer(nn.Module):
+    """reference: CLIP_ViP.py:399-467"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.embed_dim = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.self_attn = CLIPAttention(config)
+        self.layer_norm1 = nn.LayerNorm(self.embed_dim)
+        self.mlp = CLIPMLP(config)
+        self.layer_norm2 = nn.LayerNorm(self.embed_dim)
+
+    def forward(self, hidden_states, B, S, inputs_size=None, pad_mask=None):
+        return XF.encoder_layer(hidden_states, self, B, S, self.num_heads, inputs_size, pad_mask)
+
+
+class CLIPEncoder(nn.Module):
+    """reference: CLIP_ViP.py:614-712"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layers = nn.ModuleList([CLIPEncoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.gradient_checkpointing = False
+
+    def forward(self, x, B, S, inputs_size=None, pad_mask=None, collect=None):
+        for layer in self.layers:
+            x = layer(x, B, S, inputs_size, pad_mask)
+            if collect is not None:
+                collect.append(x)
+        return x
+
+
+# ------------------------------------------------------------------------------------------ towers
+class CLIPTextTransformer(nn.Module):
+    """reference: CLIP_ViP.py:715-797"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embeddings = CLIPTextEmbeddings(config)
+        self.encoder = CLIPEncoder(config)
+        self.final_layer_norm = nn.LayerNorm(config.hidden_size)
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        if input_ids is None:
+            raise ValueError("You have to specify either input_ids")
+        if output_attentions:
+            raise NotImplementedError("the fused attention kernel never materialises attention weights")
+        input_ids = input_ids.view(-1, input_ids.shape[-1]).contiguous()
+        B, Lt = input_ids.shape
+        D = self.config.hidden_size
+        x = self.embeddings(input_ids, position_ids, self.compute_dtype)
+        pad = None if attention_mask is None else attention_mask.to(torch.int64).contiguous()
+        hs = [x] if output_hidden_states else None
+        x = self.encoder(x, B, Lt, None, pad, hs)
+        # LayerNorm is row-wise, so pooling the EOT rows first and normalising only those is identical to
+        # final_layer_norm followed by the gather (:772-776); the full normalised sequence is only produced
+        # on request.
+        idx = XF.H.argmax_rows(input_ids)
+        ln = self.final_layer_norm
+        pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias)
+        last = XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D) if (output_hidden_states or return_dict is False) else None
+        return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled,
+                                          hidden_states=None if hs is None else tuple(h.view(B, Lt, D) for h in hs))
+
+
+class CLIPVisionTransformer(nn.Module):
+    """reference: CLIP_ViP.py:848-903"""
+
+    def __init__(self, config, additional_vision_config=None):
+        super().__init__()
+        self.config = config
+        self.embeddings = CLIPVisionViPEmbeddings(config, additional_vision_config)
+        self.pre_layrnorm = nn.LayerNorm(config.hidden_size)      # (sic) -- checkpoint key
+        self.encoder = CLIPEncoder(config)
+        self.post_layernorm = nn.LayerNorm(config.hidden_size)
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        if pixel_values is None:
+            raise ValueError("You have to specify pixel_values")
+        if output_attentions:
+            raise NotImplementedError("the fused attention kernel never materialises attention weights")
+        B = pixel_values.shape[0]
+        D = self.config.hidden_size
+        x, size = self.embeddings(pixel_values, self.compute_dtype)
+        S = size[0] + size[1] * size[2]
+        x = XF.LayerNormFn.apply(x, self.pre_layrnorm.weight, self.pre_layrnorm.bias)
+        hs = [x] if output_hidden_states else None
+        x = self.encoder(x, B, S, size, None, hs)
+        pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
+                                      self.post_layernorm.bias)
+        return BaseModelOutputWithPooling(last_hidden_state=x.view(B, S, D), pooler_output=pooled,
+                                          hidden_states=None if hs is None else tuple(h.view(B, S, D) for h in hs))
+
+
+# ------------------------------------------------------------------------------------------ models
+class CLIPPreTrainedModel(nn.Module):
+    """Weight init of the reference's ``_init_weights`` (CLIP_ViP.py:481-522) + local checkpoint loading."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def _init_weights(self, module):
+        factor = getattr(self.config, "initializer_factor", 1.0)
+        if isinstance(module, CLIPTextEmbeddings):
+            module.token_embedding.weight.data.normal_(mean=0.0, std=factor * 0.02)
+            module.position_embedding.weight.data.normal_(mean=0.0, std=factor * 0.02)
+        elif isinstance(module, CLIPVisionViPEmbeddings):
+            rng = module.config.initializer_range
+            nn.init.normal_(module.class_embedding, mean=0.0, std=module.embed_dim ** -0.5 * factor)
+            nn.init.normal_(module.patch_embedding.weight, std=rng * factor)
+            nn.init.normal_(module.position_embedding.weight, std=rng * factor)
+        elif isinstance(module, CLIPAttention):
+            in_std = (module.embed_dim ** -0.5) * ((2 * module.config.num_hidden_layers) ** -0.5) * factor
+            out_std = (module.embed_dim ** -0.5) * factor
+            for m in (module.q_proj, module.k_proj, module.v_proj):
+                nn.init.normal_(m.weight, std=in_std)
+            nn.init.normal_(module.out_proj.weight, std=out_std)
+        elif isinstance(module, CLIPMLP):
+            in_std = (module.config.hidden_size ** -0.5) * ((2 * module.config.num_hidden_layers) ** -0.5) * factor
+            fc_std = (2 * module.config.hidden_size) ** -0.5 * factor
+            nn.init.normal_(module.fc1.weight, std=fc_std)
+            nn.init.normal_(module.fc2.weight, std=in_std)
+        elif isinstance(module, CLIPModel):
+            nn.init.normal_(module.text_projection.weight, std=module.text_embed_dim ** -0.5 * factor)
+            nn.init.normal_(module.visual_projection.weight, std=module.vision_embed_dim ** -0.5 * factor)
+        if isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def post_init(self):
+        self.apply(self._init_weights)
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.bfloat16,):
+            raise NotImplementedError("compute dtype must be torch.bfloat16 (fp32 attention kernels are not built)")
+        for m in self.modules():
+            if hasattr(m, "compute_dtype"):
+                m.compute_dtype = dtype
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, **kw):
+        """Local-directory loader (no hub access): ``pytorch_model.bin`` / ``model.safetensors`` / a ``.pt``
+        state dict, loaded non-strictly like the reference's ``from_pretrained`` of plain CLIP weights into the
+        ViP model (new ViP parameters keep their init)."""
+        if config is None:
+            config = load_clip_config(path)
+        model = cls(config, **kw)
+        sd = None
+        cands = [path] if os.path.isfile(path) else [os.path.join(path, f) for f in
+                                                      ("pytorch_model.bin", "model.safetensors", "model.pt")]
+        for f in cands:
+            if os.path.isfile(f):
+                if f.endswith(".safetensors"):
+                    from safetensors.torch import load_file
+                    sd = load_file(f)
+                else:
+                    sd = torch.load(f, map_location="cpu")
+                break
+        if sd is None:
+            raise FileNotFoundError(f"no weights found under {path!r} (there is no hub access; pass a local directory)")
+        own = model.state_dict()
+        sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        model.load_state_dict(sd, strict=False)
+        return model
+
+
+def load_clip_config(src):
+    """``CLIPConfig`` from a directory/file with config.json, a dict, or an existing config object."""
+    if CLIPConfig is not None and isinstance(src, CLIPConfig):
+        return src
+    if isinstance(src, dict):
+        d = src
+    else:
+        f = src if os.path.isfile(src) else os.path.join(src, "config.json")
+        if not os.path.isfile(f):
+            raise FileNotFoundError(f"{f} not found: there is no hub access, clip_config must be a local directory "
+                                    "containing config.json (e.g. a copy of openai/clip-vit-base-patch16's)")
+        with open(f) as fh:
+            d = json.load(fh)
+    return CLIPConfig(text_config=dict(d.get("text_config") or {}), vision_config=dict(d.get("vision_config") or {}),
+                      projection_dim=d.get("projection_dim", 512),
+                      logit_scale_init_value=d.get("logit_scale_init_value", 2.6592))
+
+
+class CLIPTextModel(CLIPPreTrainedModel):
+    """reference: CLIP_ViP.py:800-846"""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.text_model = CLIPTextTransformer(config)
+        self.post_init()
+
+    def get_input_embeddings(self):
+        return self.text_model.embeddings.token_embedding
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        return self.text_model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                               output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                               return_dict=return_dict)
+
+
+class CLIPVisionModel(CLIPPreTrainedModel):
+    """reference: CLIP_ViP.py:906-950 (whose constructor cannot build the ViP embeddings -- fixed here by taking
+    the additional config, also looked up on ``config.vision_additional_config``)."""
+    main_input_name = "pixel_values"
+
+    def __init__(self, config, additional_vision_config=None):
+        super().__init__(config)
+        if additional_vision_config is None:
+            additional_vision_config = getattr(config, "vision_additional_config", None)
+        self.vision_model = CLIPVisionTransformer(config, additional_vision_config)
+        self.post_init()
+
+    def get_input_embeddings(self):
+        return self.vision_model.embeddings.patch_embedding
+
+    def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        return self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
+                                 output_hidden_states=output_hidden_states, return_dict=return_dict)
+
+
+def contrastive_loss(logits):
+    """reference: CLIP_ViP.py:66-67 -- CE(logits, diag).  Tiny fp32 glue used only by ``return_loss=True``
+    (VidCLIP always passes False; the training loss is ``optimization.loss.NCELearnableTempLoss``)."""
+    return F.cross_entropy(logits, torch.arange(len(logits), device=logits.device))
+
+
+def clip_loss(similarity):
+    """reference: CLIP_ViP.py:70-73"""
+    return (contrastive_loss(similarity) + contrastive_loss(similarity.T)) / 2.0
+
+
+class CLIPModel(CLIPPreTrainedModel):
+    """reference: CLIP_ViP.py:953-1172"""
+
+    def __init__(self, config):
+        super().__init__(config)
+        text_config, vision_config = config.text_config, config.vision_config
+        additional_vision_config = getattr(config, "vision_additional_config", None)
+        self.projection_dim = config.projection_dim
+        self.text_embed_dim = text_config.hidden_size
+        self.vision_embed_dim = vision_config.hidden_size
+        self.text_model = CLIPTextTransformer(text_config)
+        self.vision_model = CLIPVisionTransformer(vision_config, additional_vision_config)
+        self.visual_projection = nn.Linear(self.vision_embed_dim, self.projection_dim, bias=False)
+        self.text_projection = nn.Linear(self.text_embed_dim, self.projection_dim, bias=False)
+        self.logit_scale = nn.Parameter(torch.ones([]) * config.logit_scale_init_value)
+        self.post_init()
+
+    def get_text_features(self, input_ids=None, attention_mask=None, position_ids=None, output_attentions=None,
+                          output_hidden_states=None, return_dict=None, if_norm=None):
+        out = self.text_model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                              output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+        feats = XF.ProjectionFn.apply(out["pooler_output"], self.text_projection.weight)
+        return XF.L2NormFn.apply(feats) if if_norm else feats.float()
+
+    def get_image_features(self, pixel_values=None, output_attentions=None, output_hidden_states=None,
+                           return_dict=None, if_norm=None):
+        out = self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
+                                output_hidden_states=output_hidden_states)
+        feats = XF.ProjectionFn.apply(out["pooler_output"], self.visual_projection.weight)
+        return XF.L2NormFn.apply(feats) if if_norm else feats.float()
+
+    def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, return_loss=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None):
+        vision_outputs = self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
+                                           output_hidden_states=output_hidden_states)
+        text_outputs = self.text_model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                                       output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+        image_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(vision_outputs["pooler_output"], self.visual_projection.weight))
+        text_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(text_outputs["pooler_output"], self.text_projection.weight))
+        logits_per_text = logits_per_image = loss = None
+        if return_loss or return_dict is False or output_hidden_states:
+            # CLIP_ViP.py:1151-1158: tiny [B,B] fp32 product, only materialised on request (VidCLIP never asks)
+            logits_per_text = torch.matmul(text_embeds, image_embeds.t()) * self.logit_scale.exp()
+            logits_per_image = logits_per_text.T
+            if return_loss:   # clip_loss (:70-73) == NCELearnableTempLoss / 2, through the fused HIP loss kernel
+                loss = XF.NCELossFn.apply(image_embeds, text_embeds, self.logit_scale) * 0.5
+        return CLIPOutput(loss=loss, logits_per_image=logits_per_image, logits_per_text=logits_per_text,
+                          text_embeds=text_embeds, image_embeds=image_embeds, text_model_output=text_outputs,
+                          vision_model_output=vision_outputs)
