@@ -25,6 +25,20 @@ import torch
 import torch.nn.functional as F
 
 Tensor = torch.Tensor
+
+
+class _Rounding:
+    """Optional storage-precision emulation.  With ``ROUND.dtype = torch.bfloat16`` every tensor the HIP path
+    stores in bf16 (weights fed to GEMMs, LayerNorm outputs, q/k/v, attention output, softmax probabilities fed
+    to P.V, MLP pre-activation/activation, the residual stream) is rounded at the same point here, so a kernel
+    can be told apart from bf16 noise: HIP-vs-emulation must agree far tighter than HIP-vs-fp32.  Default: off."""
+    dtype = None
+
+    def __call__(self, t: Tensor) -> Tensor:
+        return t if self.dtype is None else t.to(self.dtype).to(t.dtype)
+
+
+ROUND = _Rounding()
 LN_EPS = 1e-5  # nn.LayerNorm default, modeling/CLIP_ViP.py:404-406,855-857
 
 
@@ -62,7 +76,7 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
     """nn.LayerNorm over the last dim, biased variance, eps 1e-5 (CLIP_ViP.py:404-406)."""
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return (x - mu) * torch.rsqrt(var + LN_EPS) * w + b
+    return ROUND((x - mu) * torch.rsqrt(var + LN_EPS) * w + b)
 
 
 def quick_gelu(x: Tensor) -> Tensor:
@@ -71,7 +85,7 @@ def quick_gelu(x: Tensor) -> Tensor:
 
 
 def linear(x: Tensor, sd: Dict[str, Tensor], name: str, bias: bool = True) -> Tensor:
-    y = x @ sd[name + ".weight"].t()
+    y = x @ ROUND(sd[name + ".weight"]).t()
     if bias:
         y = y + sd[name + ".bias"]
     return y
@@ -104,7 +118,7 @@ def proxy_attention_core(q: Tensor, k: Tensor, v: Tensor, size: Tuple[int, int, 
     of = (w @ vv).reshape(B, h, N * L, dh)
     wp = torch.softmax(q[:, :, :M] @ k.transpose(-1, -2), dim=-1)  # [B,h,M,S]
     op = wp @ v
-    return torch.cat([op, of], dim=2)
+    return ROUND(torch.cat([op, of], dim=2))
 
 
 def proxy_attention_core_masked(q: Tensor, k: Tensor, v: Tensor, size: Tuple[int, int, int]) -> Tensor:
@@ -132,7 +146,7 @@ def masked_attention_core(q: Tensor, k: Tensor, v: Tensor, pad_mask: Optional[Te
     if pad_mask is not None:
         inv = 1.0 - pad_mask.to(s.dtype)[:, None, None, :]
         s = s + inv.masked_fill(inv.bool(), torch.finfo(s.dtype).min)
-    return torch.softmax(s, dim=-1) @ v
+    return ROUND(torch.softmax(s, dim=-1) @ v)
 
 
 def attention_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int,
@@ -141,9 +155,9 @@ def attention_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int,
     core attention, head merge, out_proj (:379 / :328)."""
     B, S, D = x.shape
     dh = D // heads
-    q = _heads(linear(x, sd, pfx + "q_proj") * dh ** -0.5, heads)
-    k = _heads(linear(x, sd, pfx + "k_proj"), heads)
-    v = _heads(linear(x, sd, pfx + "v_proj"), heads)
+    q = _heads(ROUND(linear(x, sd, pfx + "q_proj") * dh ** -0.5), heads)
+    k = _heads(ROUND(linear(x, sd, pfx + "k_proj")), heads)
+    v = _heads(ROUND(linear(x, sd, pfx + "v_proj")), heads)
     if size is not None:
         o = proxy_attention_core(q, k, v, size)
     else:
@@ -157,10 +171,10 @@ def encoder_layer(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int,
                   size: Optional[Tuple[int, int, int]], pad_mask: Optional[Tensor]) -> Tensor:
     """Pre-LN block, CLIPEncoderLayer.forward else-branch (CLIP_ViP.py:444-460)."""
     h = layer_norm(x, sd[pfx + "layer_norm1.weight"], sd[pfx + "layer_norm1.bias"])
-    x = x + attention_block(h, sd, pfx + "self_attn.", heads, size, pad_mask)
+    x = ROUND(x + attention_block(h, sd, pfx + "self_attn.", heads, size, pad_mask))
     h = layer_norm(x, sd[pfx + "layer_norm2.weight"], sd[pfx + "layer_norm2.bias"])
-    h = linear(quick_gelu(linear(h, sd, pfx + "mlp.fc1")), sd, pfx + "mlp.fc2")   # CLIPMLP :392-396
-    return x + h
+    h = linear(ROUND(quick_gelu(linear(h, sd, pfx + "mlp.fc1"))), sd, pfx + "mlp.fc2")   # CLIPMLP :392-396
+    return ROUND(x + h)
 
 
 def encoder(x: Tensor, sd: Dict[str, Tensor], pfx: str, cfg: TowerCfg,
@@ -192,8 +206,8 @@ def vip_embeddings(video: Tensor, sd: Dict[str, Tensor], cfg: OracleCfg):
     gh, gw = H // P, W // P
     wconv = sd["vision_model.embeddings.patch_embedding.weight"]      # [D,3,P,P]
     D = wconv.shape[0]
-    patches = video.reshape(B, T, C, gh, P, gw, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, gh * gw, C * P * P)
-    pe = patches @ wconv.reshape(D, -1).t()                           # [B,T,L,D]
+    patches = ROUND(video.reshape(B, T, C, gh, P, gw, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, gh * gw, C * P * P))
+    pe = patches @ ROUND(wconv.reshape(D, -1)).t()                    # [B,T,L,D]
     pos = sd["vision_model.embeddings.position_embedding.weight"]     # [1+L,D]
     if cfg.use_temporal_embed:
         pe = pe + temporal_table(sd, T)[None, :, None, :]
@@ -201,7 +215,7 @@ def vip_embeddings(video: Tensor, sd: Dict[str, Tensor], cfg: OracleCfg):
     cls = sd["vision_model.embeddings.class_embedding"][None, None, :].expand(B, 1, D) + pos[0]
     add = sd["vision_model.embeddings.added_cls"][None].expand(B, -1, D) + pos[0]
     M = 1 + add.shape[1]
-    x = torch.cat([cls, add, pe.reshape(B, T * gh * gw, D)], dim=1)
+    x = ROUND(torch.cat([cls, add, pe.reshape(B, T * gh * gw, D)], dim=1))
     return x, (M, T, gh * gw)
 
 
@@ -224,8 +238,8 @@ def text_tower(ids: Tensor, mask: Optional[Tensor], sd: Dict[str, Tensor], cfg: 
     """CLIPTextTransformer.forward (CLIP_ViP.py:726-786): token+position gather (:210-227),
     causal+padding masks, encoder, final_layer_norm, pooled = hidden at ids.argmax(-1)."""
     B, Lt = ids.shape
-    x = sd["text_model.embeddings.token_embedding.weight"][ids] \
-        + sd["text_model.embeddings.position_embedding.weight"][:Lt][None]
+    x = ROUND(sd["text_model.embeddings.token_embedding.weight"][ids]
+              + sd["text_model.embeddings.position_embedding.weight"][:Lt][None])
     if collect is not None:
         collect.append(x)
     x = encoder(x, sd, "text_model.encoder.", cfg.text, None, mask, collect)
@@ -245,8 +259,8 @@ def clip_features(video: Tensor, ids: Tensor, mask: Optional[Tensor], sd: Dict[s
     CLIP_ViP.py:1125-1149).  Returns (vis_features, text_features), unit-norm [B,proj]."""
     _, vp = vision_tower(video, sd, cfg)
     _, tp = text_tower(ids, mask, sd, cfg)
-    vis = l2_normalize(vp @ sd["visual_projection.weight"].t())
-    txt = l2_normalize(tp @ sd["text_projection.weight"].t())
+    vis = l2_normalize(ROUND(vp @ ROUND(sd["visual_projection.weight"]).t()))
+    txt = l2_normalize(ROUND(tp @ ROUND(sd["text_projection.weight"]).t()))
     return vis, txt
 
 

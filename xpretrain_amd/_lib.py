@@ -5,6 +5,13 @@ Loading fails loudly if it is missing -- there is no fallback path.
 """
 import ctypes as C
 import os
+import sys
+
+# PyTorch must be imported BEFORE the library is dlopen'ed: torch bundles its own HIP runtime
+# (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Loaded first, it satisfies our DT_NEEDED by soname and
+# the process has ONE runtime / one set of streams; loaded second, torch would bring a second runtime whose
+# streams are not ordered with ours.
+import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxpretrain_hip.so")
@@ -92,6 +99,13 @@ def lib():
     return _lib
 
 
+DEBUG_SYNC = bool(int(os.environ.get("XPRETRAIN_DEBUG_SYNC", "0")))
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed (rc={rc}): {lib().xp_last_error().decode()}")
+    if DEBUG_SYNC:      # debugging aid: localise an asynchronous fault to the call that caused it
+        sys.stderr.write(f"[xp] {what} ... "); sys.stderr.flush()
+        torch.cuda.synchronize()
+        sys.stderr.write("ok\n"); sys.stderr.flush()

@@ -84,7 +84,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, 
         ws = H.workspace(split * n_out * n_in * 4, dy.device, "splitk")
         H.gemm(dy, x, n_out, n_in, rows, a_kstrided=True, b_kstrided=True, lda=n_out, ldb=n_in, out=ws,
                split_k=split, a_remap=a_remap)
-        H.splitk_reduce(ws, dw)
+        H.splitk_reduce(ws, dw, splits=split)
     return dw
 
 

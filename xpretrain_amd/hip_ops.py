@@ -92,9 +92,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     return out
 
 
-def splitk_reduce(slabs: torch.Tensor, out: torch.Tensor, accumulate=False) -> torch.Tensor:
+def splitk_reduce(slabs: torch.Tensor, out: torch.Tensor, accumulate=False, splits=None) -> torch.Tensor:
     n = out.numel()
-    L.check(L.lib().xp_splitk_reduce(_p(slabs), _p(out), n, slabs.numel() // n, int(accumulate), _stream()),
+    if splits is None:
+        if slabs.dtype != torch.float32:
+            raise TypeError("splitk_reduce: pass `splits` explicitly when the slab buffer is an untyped workspace")
+        splits = slabs.numel() // n
+    L.check(L.lib().xp_splitk_reduce(_p(slabs), _p(out), n, splits, int(accumulate), _stream()),
             "xp_splitk_reduce")
     return out
 
