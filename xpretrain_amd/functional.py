@@ -13,6 +13,7 @@ Reference call sites are cited per class (paths relative to /root/reference/CLIP
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -29,15 +30,21 @@ class WeightCache:
     def __init__(self):
         self._c = {}
 
+    @staticmethod
+    def _alive(ent, ws) -> bool:
+        """ids are only unique among LIVE objects: an entry is valid only while its weak references still point at
+        the very tensors being asked about (a freed model's id can be reused by a new parameter)."""
+        return ent is not None and all(r() is w for r, w in zip(ent[2], ws))
+
     def get(self, w: torch.Tensor, dtype) -> torch.Tensor:
         if dtype == torch.float32:
             return w.detach()
         key = (id(w), dtype)
         ent = self._c.get(key)
         ver = (w._version, w.data_ptr())
-        if ent is None or ent[0] != ver:
-            buf = ent[1] if ent is not None and ent[1].shape == w.shape else None
-            ent = (ver, H.cast(w.detach(), dtype, out=buf))
+        if not self._alive(ent, (w,)) or ent[0] != ver:
+            buf = ent[1] if ent is not None and ent[1].shape == w.shape and ent[1].device == w.device else None
+            ent = (ver, H.cast(w.detach(), dtype, out=buf), (weakref.ref(w),))
             self._c[key] = ent
         return ent[1]
 
@@ -46,15 +53,16 @@ class WeightCache:
         key = (tuple(id(w) for w in ws), dtype)
         ver = tuple((w._version, w.data_ptr()) for w in ws)
         ent = self._c.get(key)
-        if ent is None or ent[0] != ver:
+        if not self._alive(ent, ws) or ent[0] != ver:
             rows = sum(w.shape[0] for w in ws)
-            buf = ent[1] if ent is not None else torch.empty((rows,) + tuple(ws[0].shape[1:]), dtype=dtype,
-                                                              device=ws[0].device)
+            shape = (rows,) + tuple(ws[0].shape[1:])
+            reuse = ent is not None and tuple(ent[1].shape) == shape and ent[1].device == ws[0].device
+            buf = ent[1] if reuse else torch.empty(shape, dtype=dtype, device=ws[0].device)
             r = 0
             for w in ws:
                 H.cast(w.detach(), dtype, out=buf[r:r + w.shape[0]])
                 r += w.shape[0]
-            ent = (ver, buf)
+            ent = (ver, buf, tuple(weakref.ref(w) for w in ws))
             self._c[key] = ent
         return ent[1]
 
