@@ -14,6 +14,7 @@
 // are NOT transposed in memory: they are staged as [k][row] tiles and read with ds_read_b64_tr_b16
 // (bf16) / ds_read_b32 (f32), which deliver exactly the MFMA fragment.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -106,6 +107,62 @@ __device__ __forceinline__ void lstore_ks(char* tile, const u32x4 (&r)[4], int t
   }
 }
 
+// ---- fast staging: global -> LDS directly (buffer_load ... lds, 16 B per lane, no VGPR round trip, no ds_write) --
+// One wave instruction fills 1 KiB of LDS lane-linearly (base + lane*16), so the tile image is the same as
+// the register-staged one only if the XOR swizzle is applied to the per-lane GLOBAL source address.  The buffer
+// descriptor's bounds check zero-fills rows / k-rows beyond the operand (no branches for the M and split-K tails).
+// Preconditions (checked on the host): dense operand, no row remap, k-contiguous: K % (128/sizeof T) == 0;
+// k-strided: rows % 128 == 0; operand bytes < 4 GiB.
+typedef __attribute__((address_space(3))) char lds_char;
+
+template <typename T, bool KS>
+struct GldsStager {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[4];     // per-lane byte offset of pass j at k-tile 0
+  unsigned step;        // byte advance per k-tile
+  unsigned lds_wave;    // wave-uniform byte offset of this wave's 1 KiB slot inside a 4 KiB pass
+
+  __device__ __forceinline__ void init(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t K, int64_t kbeg,
+                                       int lane, int wave) {
+    constexpr int ES = sizeof(T);
+    const int64_t bytes = (KS ? K : rows) * ld * ES;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (unsigned)bytes, 0x00020000);
+    lds_wave = wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t off;
+      if constexpr (!KS) {
+        const int row = j * 32 + wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz128(row);
+        off = ((row0 + row) * ld + kbeg) * ES + c * 16;
+      } else if constexpr (sizeof(T) == 2) {
+        const int kr = j * 16 + wave * 4 + (lane >> 4), c16 = lane & 15;
+        const int src = (((c16 >> 1) ^ ks_f(kr)) << 1) | (c16 & 1);
+        off = ((kbeg + kr) * ld + row0) * ES + src * 16;
+      } else {
+        const int kr = j * 8 + wave * 2 + (lane >> 5), c32 = lane & 31;
+        const int col = (c32 * 4) ^ (((kr >> 2) & 1) << 4);
+        off = ((kbeg + kr) * ld + row0 + col) * ES;
+      }
+      // anything past the end must stay past the end after the 32-bit cast
+      voff[j] = off >= bytes ? 0xFFFFFFF0u : (unsigned)off;
+    }
+    constexpr int KE = BKB / ES;
+    step = (unsigned)((KS ? (int64_t)KE * ld : (int64_t)KE) * ES);
+  }
+  // issue the 4 DMA passes of k-tile kt into `tile` (16 KiB)
+  __device__ __forceinline__ void issue(char* tile, int kt) const {
+    lds_char* t3 = (lds_char*)tile;
+    const unsigned adv = (unsigned)kt * step;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned o = voff[j] + adv;
+      if (o < voff[j]) o = 0xFFFFFFF0u;       // wrapped: was (and stays) out of bounds
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, t3 + (j * 4096 + lds_wave), 16, o, 0, 0, 0);
+    }
+  }
+};
+
 // ---- fragments: LDS -> registers ------------------------------------------------------------------
 // ot: 16-row sub-tile index (0..7) inside the 128-row tile; ks: 64-byte k super-step (0..1).
 template <typename T, bool KS>
@@ -137,7 +194,7 @@ __device__ __forceinline__ typename Frag<T>::type lfrag(const char* tile, int ot
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
-template <typename T, bool AKS, bool BKS>
+template <typename T, bool AKS, bool BKS, bool GLDS>
 __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto sA = [&](int s) -> char* { return smem + (2 * s) * TILE_BYTES; };
@@ -184,7 +241,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
     if constexpr (BKS) lstore_ks<T>(sB(s), rb, tid); else lstore_kc<T>(sB(s), rb, tid);
   };
 
-  if (nk > 0) {
+  GldsStager<T, AKS> ga;
+  GldsStager<T, BKS> gb;
+  if constexpr (GLDS) {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    ga.init(A, p.lda, m0, p.M, kend, kbeg, lane, wv);
+    gb.init(B, p.ldb, n0, p.N, kend, kbeg, lane, wv);
+    if (nk > 0) { ga.issue(sA(0), 0); gb.issue(sB(0), 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (nk > 0) {
     gload(kbeg);
     lstore(0);
   }
@@ -192,7 +257,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int s = kt & 1;
-    if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * KE);
+    if constexpr (GLDS) {
+      if (kt + 1 < nk) { ga.issue(sA(s ^ 1), kt + 1); gb.issue(sB(s ^ 1), kt + 1); }
+    } else {
+      if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * KE);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       typename Frag<T>::type fw[4], fx[4];
@@ -205,68 +274,101 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
     }
-    if (kt + 1 < nk) lstore(s ^ 1);
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (kt + 1 < nk) lstore(s ^ 1);
+    }
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns n = nb + 0..3 for row m -------------------------------------------------
-  const int i16 = lane & 15, g = lane >> 4;
+  // ---- epilogue ---------------------------------------------------------------------------------------
+  // The accumulator lane owns 4 consecutive n of ONE row, i.e. a wave store would touch 16 rows x 32 B.  Instead
+  // the raw fp32 tile is staged through the (now idle) 64 KiB of LDS -- [128][128] fp32, 16-byte chunks XOR-
+  // swizzled by (row & 7) -- and read back row-major: 32 lanes cover one 512-byte fp32 row, so bias / residual /
+  // table loads and the bf16 stores are full-line, fully coalesced accesses.  All epilogue math is fp32.
+  {
+    const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = wm * 64 + mt * 16 + i16;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int chunk = wn * 16 + nt * 4 + g;
+        *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[nt][mt];
+      }
+    }
+  }
+  __syncthreads();
+
   const int ep = p.epilogue;
+  const int c = tid & 31, r8 = tid >> 5;
+  const int64_t n = n0 + c * 4;
+  if (n >= p.N) return;
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
+  const bool has_bias = ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID;
+  const f32x4 bias = has_bias ? load4(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float colscale = ep == XP_EPI_SCALE ? p.scale : ((ep == XP_EPI_BIAS_QSCALE && n < p.scale_cols) ? p.scale : 1.0f);
 
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int64_t m = m0 + wm * 64 + mt * 16 + i16;
-    if (m >= p.M) continue;
+#pragma unroll 4
+  for (int pass = 0; pass < 16; ++pass) {
+    const int row = pass * 8 + r8;
+    const int64_t m = m0 + row;
+    if (m >= p.M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((c ^ (row & 7)) << 4));
+    v = (v + bias) * colscale;
     const int64_t crow = p.cmap(m);
-    int64_t tt = 0, ll = 0;
-    if (ep == XP_EPI_PATCH) {
+    if (ep == XP_EPI_BIAS_GELU) {
+      if (p.out_f32) store4(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
+      else           store4(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+    } else if (ep == XP_EPI_BIAS_RESID) {
+      v += load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+    } else if (ep == XP_EPI_GELU_BWD) {
+      const f32x4 pre = load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(pre[e]);
+    } else if (ep == XP_EPI_PATCH) {
       const int64_t w = p.cmap.grp ? (m % p.cmap.grp) : m;
-      tt = w / p.tab_L; ll = w % p.tab_L;
+      v += load4(p.tab1 + (w / p.tab_L) * p.N + n);
+      v += load4(p.tab2 + (w % p.tab_L) * p.N + n);
     }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int64_t n = n0 + wn * 64 + nt * 16 + g * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[nt][mt];
-      if (ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID) {
-        const f32x4 b = load4(p.bias + n);
-        v += b;
-      }
-      if (ep == XP_EPI_BIAS_QSCALE) {
-        if (n < p.scale_cols) v *= p.scale;
-      } else if (ep == XP_EPI_SCALE) {
-        v *= p.scale;
-      } else if (ep == XP_EPI_BIAS_GELU) {
-        if (p.out_f32) store4(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
-        else           store4(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
-      } else if (ep == XP_EPI_BIAS_RESID) {
-        v += load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
-      } else if (ep == XP_EPI_GELU_BWD) {
-        const f32x4 pre = load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(pre[e]);
-      } else if (ep == XP_EPI_PATCH) {
-        v += load4(p.tab1 + tt * p.N + n);
-        v += load4(p.tab2 + ll * p.N + n);
-      }
-      if (p.out_f32) store4(Cf + crow * p.ldc + n, v);
-      else           store4(Ct + crow * p.ldc + n, v);
-    }
+    if (p.out_f32) store4(Cf + crow * p.ldc + n, v);
+    else           store4(Ct + crow * p.ldc + n, v);
   }
+}
+
+template <typename T, bool GLDS>
+void launch2(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
+  const size_t lds = 4 * TILE_BYTES;
+  if (!d->a_kstrided && !d->b_kstrided)      gemm_kernel<T, false, false, GLDS><<<grid, NT, lds, st>>>(kp);
+  else if (!d->a_kstrided && d->b_kstrided)  gemm_kernel<T, false, true, GLDS><<<grid, NT, lds, st>>>(kp);
+  else if (d->a_kstrided && d->b_kstrided)   gemm_kernel<T, true, true, GLDS><<<grid, NT, lds, st>>>(kp);
+  else                                       gemm_kernel<T, true, false, GLDS><<<grid, NT, lds, st>>>(kp);
+}
+
+// The direct-to-LDS path needs dense, un-remapped operands whose tails the buffer bounds check can zero-fill.
+bool glds_ok(const XpGemmDesc* d, int esz) {
+  if (getenv("XPRETRAIN_GEMM_NO_GLDS")) return false;
+  if (d->a_grp != 0) return false;
+  const int64_t ke = BKB / esz;
+  const int64_t a_rows = d->a_kstrided ? d->K : d->M, b_rows = d->b_kstrided ? d->K : d->N;
+  if (!d->a_kstrided && (d->K % ke != 0 || d->lda != d->K)) return false;
+  if (!d->b_kstrided && (d->K % ke != 0 || d->ldb != d->K)) return false;
+  if (d->a_kstrided && (d->M % BM != 0 || d->lda != d->M)) return false;
+  if (d->b_kstrided && (d->N % BN != 0 || d->ldb != d->N)) return false;
+  const int64_t lim = (int64_t)0xFFFFFFF0u - 256 * 1024 * 1024;
+  if ((a_rows + BM) * d->lda * esz >= lim || (b_rows + BN) * d->ldb * esz >= lim) return false;
+  return true;
 }
 
 template <typename T>
 int launch(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
-  const size_t lds = 4 * TILE_BYTES;
-  if (!d->a_kstrided && !d->b_kstrided)      gemm_kernel<T, false, false><<<grid, NT, lds, st>>>(kp);
-  else if (!d->a_kstrided && d->b_kstrided)  gemm_kernel<T, false, true><<<grid, NT, lds, st>>>(kp);
-  else if (d->a_kstrided && d->b_kstrided)   gemm_kernel<T, true, true><<<grid, NT, lds, st>>>(kp);
-  else                                       gemm_kernel<T, true, false><<<grid, NT, lds, st>>>(kp);
+  if (glds_ok(d, sizeof(T))) launch2<T, true>(d, kp, grid, st);
+  else                       launch2<T, false>(d, kp, grid, st);
   return 0;
 }
 
@@ -274,9 +376,16 @@ int launch(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n4,
                                      int splits, int accumulate) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const f32x4* sl = reinterpret_cast<const f32x4*>(slabs);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 s = accumulate ? reinterpret_cast<const f32x4*>(out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < splits; ++z) s += reinterpret_cast<const f32x4*>(slabs)[(int64_t)z * n4 + i];
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {         // 4 independent 16-byte loads in flight per lane
+      const f32x4 a = sl[(int64_t)z * n4 + i], b = sl[(int64_t)(z + 1) * n4 + i];
+      const f32x4 c = sl[(int64_t)(z + 2) * n4 + i], d = sl[(int64_t)(z + 3) * n4 + i];
+      s += (a + b) + (c + d);
+    }
+    for (; z < splits; ++z) s += sl[(int64_t)z * n4 + i];
     reinterpret_cast<f32x4*>(out)[i] = s;
   }
 }
@@ -349,7 +458,7 @@ extern "C" int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32
                                 void* stream) {
   XP_REQUIRE(slabs && out && n > 0 && n % 4 == 0 && splits >= 1, "xp_splitk_reduce: bad arguments");
   const int64_t n4 = n / 4;
-  int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
+  int blocks = (int)(cdiv(n4, 256) < 8192 ? cdiv(n4, 256) : 8192);
   splitk_reduce_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(slabs, out, n4, splits, accumulate);
   XP_CHECK_LAUNCH("xp_splitk_reduce");
   return XP_OK;

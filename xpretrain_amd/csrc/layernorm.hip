@@ -126,18 +126,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
 }
 
 // out_g[c] (+)= sum_b part[b][0][c]; out_b[c] (+)= sum_b part[b][1][c]
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int nblocks,
-                                       int cols, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * cols) return;
-  const int which = c / cols, col = c % cols;
+// 64 columns per block; 4 waves each sum a quarter of the partial rows (coalesced 256-byte reads), LDS combine.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta,
+                                                              int nblocks, int cols, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;                 // index into the concatenated [2*cols] (gamma | beta)
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[((int64_t)b * 2 + which) * cols + col];
-  float* out = which ? dbeta : dgamma;
-  out[col] = accumulate ? out[col] + s : s;
+  if (c < 2 * cols) {
+    const int which = c / cols, col = c % cols;
+    for (int b = w; b < nblocks; b += 4) s += part[((int64_t)b * 2 + which) * cols + col];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < 2 * cols) {
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    const int which = c / cols, col = c % cols;
+    float* out = which ? dbeta : dgamma;
+    out[col] = accumulate ? out[col] + t : t;
+  }
 }
 
-inline int bwd_blocks(int64_t rows) { int64_t b = cdiv(rows, WAVES * 8); return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
+inline int bwd_blocks(int64_t rows) { int64_t b = cdiv(rows, WAVES * 4); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 
 }  // namespace
 
@@ -183,7 +193,7 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                                                  (const float*)dres, lddres, (float*)dx, lddx, part, rows, (int)cols);
   else XP_REQUIRE(false, "xp_layernorm_bwd: bad dtype %d", dtype);
   XP_CHECK_LAUNCH("xp_layernorm_bwd");
-  ln_param_reduce_kernel<<<(unsigned)cdiv(2 * cols, 256), 256, 0, st>>>(part, dgamma, dbeta, blocks, (int)cols, accumulate);
+  ln_param_reduce_kernel<<<(unsigned)cdiv(2 * cols, 64), 256, 0, st>>>(part, dgamma, dbeta, blocks, (int)cols, accumulate);
   XP_CHECK_LAUNCH("xp_layernorm_bwd(reduce)");
   return XP_OK;
 }
