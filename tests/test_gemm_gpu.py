@@ -124,3 +124,71 @@ def test_bad_arguments_raise():
     A = torch.zeros(8, 12, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError, match="multiples of"):
         H.gemm(A, A, 8, 8, 12)
+
+
+# ---------------------------------------------------------------------------------------------- 256x256 family
+@pytest.fixture
+def force_gemm256(monkeypatch):
+    monkeypatch.setenv("XPRETRAIN_GEMM256", "2")     # use the deep-pipelined family whenever its preconditions hold
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1280, 512, 768), (1100, 768, 256), (300, 260, 96), (2356, 768, 3072)])
+def test_gemm256_nt(force_gemm256, dtype, M, N, K):
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(M + N + K)
+    A, B = _mk((M, K), dtype), _mk((N, K), dtype)
+    C = H.gemm(A, B, M, N, K)
+    ref = A.double() @ B.double().t()
+    assert report(f"gemm256_nt {dtype} {M}x{N}x{K}", C, ref, TOL[dtype]) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1280, 768, 2304), (520, 256, 72), (2356, 3072, 768)])
+def test_gemm256_nn(force_gemm256, dtype, M, N, K):
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(1)
+    A, W = _mk((M, K), dtype), _mk((K, N), dtype)
+    C = H.gemm(A, W, M, N, K, b_kstrided=True)
+    ref = A.double() @ W.double()
+    assert report(f"gemm256_nn {dtype} {M}x{N}x{K}", C, ref, TOL[dtype]) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,split", [(768, 1024, 1000, 1), (256, 512, 77, 1), (768, 768, 4000, 8)])
+def test_gemm256_tn(force_gemm256, dtype, M, N, K, split):
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(2)
+    Y, X = _mk((K, M), dtype), _mk((K, N), dtype)
+    if split == 1:
+        C = H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, out_dtype=torch.float32)
+    else:
+        C = H.splitk_reduce(H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, split_k=split), torch.empty(M, N, device="cuda"))
+    ref = Y.double().t() @ X.double()
+    assert report(f"gemm256_tn {dtype} {M}x{N}x{K} split{split}", C, ref, 2e-5) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm256_epilogues(force_gemm256, dtype):
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(3)
+    M, N, K = 1100, 512, 192
+    A, B = _mk((M, K), dtype, 0.5), _mk((N, K), dtype, 0.2)
+    bias = torch.randn(N, device="cuda")
+    R = _mk((M, N), dtype)
+    acc = A.double() @ B.double().t()
+    tol = TOL[dtype]
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=128)
+    ref = acc + bias.double(); ref[:, :128] *= 0.125
+    assert report(f"g256 epi_qscale {dtype}", C, ref, tol) <= tol
+    aux = torch.empty(M, N, dtype=dtype, device="cuda")
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    pre = acc + bias.double()
+    assert report(f"g256 epi_gelu.aux {dtype}", aux, pre, tol) <= tol
+    assert report(f"g256 epi_gelu.act {dtype}", C, pre * torch.sigmoid(1.702 * pre), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R)
+    assert report(f"g256 epi_resid {dtype}", C, acc + bias.double() + R.double(), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_GELU_BWD, resid=R)
+    x = R.double(); s = torch.sigmoid(1.702 * x)
+    assert report(f"g256 epi_gelu_bwd {dtype}", C, acc * (s * (1 + 1.702 * x * (1 - s))), tol) <= tol

@@ -14,33 +14,15 @@
 // are NOT transposed in memory: they are staged as [k][row] tiles and read with ds_read_b64_tr_b16
 // (bf16) / ds_read_b32 (f32), which deliver exactly the MFMA fragment.
 #include "common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
 
+using namespace xpgemm;
 constexpr int BM = 128, BN = 128, BKB = 128;   // BKB: bytes of k per stage
 constexpr int NT = 256;
 constexpr int TILE_BYTES = 128 * 128;          // one operand tile per stage (16 KiB)
-
-struct Remap {
-  int64_t grp, stride, off;
-  __device__ __forceinline__ int64_t operator()(int64_t r) const {
-    return grp == 0 ? r : (r / grp) * stride + off + (r % grp);
-  }
-};
-
-struct KParams {
-  const void* A; const void* B; void* C;
-  int64_t M, N, K, lda, ldb, ldc;
-  Remap amap, cmap;
-  int epilogue, out_f32;
-  int64_t k_per_split;
-  const float* bias; float scale; int64_t scale_cols;
-  const void* resid; int64_t ldr;
-  void* aux; int64_t ldaux;
-  const float* tab1; const float* tab2; int64_t tab_L;
-  int tiles_m, tiles_n;
-};
 
 // ---- staging: global -> registers (4 x 16 B per thread per operand) -------------------------------
 // k-contiguous operand: tile = [128 rows][128 B of k].
@@ -72,7 +54,6 @@ __device__ __forceinline__ void lstore_kc(char* tile, const u32x4 (&r)[4], int t
 // k-strided operand: storage [k][row]; tile = [KE k-rows][128 rows]  (KE = 64 bf16 / 32 f32).
 //   bf16: 256-byte k-rows, 32-byte blocks (16 rows) XOR-swizzled by f(k) = (k&3) | ((k>>3)&1)<<2
 //   f32 : 512-byte k-rows, column XOR ((k>>2)&1)<<4
-__device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 template <typename T>
 __device__ __forceinline__ void gload_ks(u32x4 (&r)[4], const T* base, int64_t ld, int64_t row0, int64_t rows,
@@ -308,36 +289,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
-  const bool has_bias = ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID;
-  const f32x4 bias = has_bias ? load4(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const float colscale = ep == XP_EPI_SCALE ? p.scale : ((ep == XP_EPI_BIAS_QSCALE && n < p.scale_cols) ? p.scale : 1.0f);
+  const EpiLane el(p, n);
 
 #pragma unroll 4
   for (int pass = 0; pass < 16; ++pass) {
     const int row = pass * 8 + r8;
     const int64_t m = m0 + row;
     if (m >= p.M) break;
-    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((c ^ (row & 7)) << 4));
-    v = (v + bias) * colscale;
-    const int64_t crow = p.cmap(m);
-    if (ep == XP_EPI_BIAS_GELU) {
-      if (p.out_f32) store4(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
-      else           store4(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
-    } else if (ep == XP_EPI_BIAS_RESID) {
-      v += load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
-    } else if (ep == XP_EPI_GELU_BWD) {
-      const f32x4 pre = load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(pre[e]);
-    } else if (ep == XP_EPI_PATCH) {
-      const int64_t w = p.cmap.grp ? (m % p.cmap.grp) : m;
-      v += load4(p.tab1 + (w / p.tab_L) * p.N + n);
-      v += load4(p.tab2 + (w % p.tab_L) * p.N + n);
-    }
-    if (p.out_f32) store4(Cf + crow * p.ldc + n, v);
-    else           store4(Ct + crow * p.ldc + n, v);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((c ^ (row & 7)) << 4));
+    epi_row<T>(p, el, v, m, n, Cf, Ct);
   }
 }
 
@@ -448,6 +408,10 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
              split, (long long)d->K, zsplits);
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   hipStream_t st = (hipStream_t)stream;
+  if ((split == 1 || getenv("XPRETRAIN_GEMM256_SPLITK")) && xp_gemm256_try(d, kp, st)) {     // large dense problems: 256x256 deep-pipelined family
+    XP_CHECK_LAUNCH("xp_gemm(256)");
+    return XP_OK;
+  }
   if (d->in_dtype == XP_BF16) launch<bf16_t>(d, kp, grid, st);
   else                        launch<float>(d, kp, grid, st);
   XP_CHECK_LAUNCH("xp_gemm");
