@@ -152,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (no sync): launch-bound if ~= dt
     sync()
     dt = time.perf_counter() - t0
     if W > 1:
@@ -189,6 +190,7 @@ def main():
                        "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4)},
             "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
             "step_frac_of_bf16_peak": round(step_flops / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
             "vit_forward_ms": round(vit_fwd_ms, 3),
             "vit_forward_frac_of_bf16_peak": round(f_vis * a.batch / (vit_fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16,NT> fc1 +bias+quick_gelu "

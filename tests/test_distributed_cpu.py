@@ -33,6 +33,7 @@ def _worker(rank, world, port, q):
     assert len(red.buckets) >= 2
     for step in range(2):                       # second step checks zero_grad / bucket reuse
         red.zero_grad()
+        assert Wv.grad is None
         vis = torch.nn.functional.normalize(xv @ Wv, dim=-1); txt = torch.nn.functional.normalize(xt @ Wt, dim=-1)
         gv, gt = D.gather_features(vis, txt, verify_identical=True)
         loss = O.nce_learnable_temp_loss(gv, gt, ls)

@@ -71,9 +71,28 @@ def bench_ln():
     print(f"layernorm bwd {M}x{D}: {us:7.1f} us  {M*D*8/us/1e3:7.1f} GB/s")
 
 
+def bench_attn():
+    B, Hh, M, N, Lp = 8, 12, 4, 12, 196
+    S = M + N * Lp
+    qkv = torch.randn(B * S, 3 * Hh * 64, device="cuda").to(torch.bfloat16)
+    us = timeit(lambda: H.attn_fwd(qkv, B, S, Hh, size=(M, N, Lp)))
+    flops = 4 * N * Lp * (M + Lp) * 64 * Hh * B + 4 * M * S * 64 * Hh * B
+    print(f"attn fwd  B{B} H{Hh} (4,12,196): {us:7.1f} us  {flops/us/1e6:6.1f} TFLOP/s  {4*B*S*Hh*64*2/us/1e3:7.1f} GB/s")
+    out, stats = H.attn_fwd(qkv, B, S, Hh, size=(M, N, Lp))
+    dout = torch.randn_like(out)
+    us = timeit(lambda: H.attn_bwd(qkv, out, dout, stats, B, S, Hh, size=(M, N, Lp), q_scale=0.125))
+    print(f"attn bwd  B{B} H{Hh} (4,12,196): {us:7.1f} us  {2.5*flops/us/1e6:6.1f} TFLOP/s")
+    ids_mask = torch.ones(8, 32, dtype=torch.int64, device="cuda")
+    q2 = torch.randn(8 * 32, 3 * 8 * 64, device="cuda").to(torch.bfloat16)
+    us = timeit(lambda: H.attn_fwd(q2, 8, 32, 8, pad_mask=ids_mask))
+    print(f"attn fwd  text B8 H8 S32: {us:7.1f} us")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("ln", "all"):
         bench_ln()
+    if what in ("attn", "all"):
+        bench_attn()

@@ -350,18 +350,53 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
   }
 }
 
-constexpr int CS_ROWS = 64;    // rows per colsum block
+// Column sums (bias gradients): block = 4 waves; wave w sums rows r0+w, r0+w+4, ... of a CS_ROWS-row chunk for 256
+// columns (4 per lane, 8/16-byte loads, 512 B contiguous per wave instruction), 4-deep independent accumulators;
+// LDS combine of the 4 waves; one partial row per chunk -> splitk_reduce.  Grid: (cols/256, rows/CS_ROWS).
+constexpr int CS_ROWS = 32;
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
-                                      float* __restrict__ part) {
-  // block: 64 threads x 4 columns each = 256 columns; gridDim.y row chunks
-  const int64_t c = ((int64_t)blockIdx.x * 64 + threadIdx.x) * 4;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
+                                                             float* __restrict__ part) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
   const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
   const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = r0; r < r1; ++r) s += load4(X + r * ldx + c);
-  store4(part + (int64_t)blockIdx.y * cols + c, s);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (c < cols) {
+    int64_t r = r0 + w;
+    for (; r + 4 < r1; r += 8) { s0 += load4(X + r * ldx + c); s1 += load4(X + (r + 4) * ldx + c); }
+    if (r < r1) s0 += load4(X + r * ldx + c);
+  }
+  store4(&red[w][lane * 4], s0 + s1);
+  __syncthreads();
+  if (w == 0 && c < cols) {
+    const f32x4 t = load4(&red[0][lane * 4]) + load4(&red[1][lane * 4]) + load4(&red[2][lane * 4]) + load4(&red[3][lane * 4]);
+    store4(part + (int64_t)blockIdx.y * cols + c, t);
+  }
+}
+
+// out[y][c] (+)= sum of `nsum` consecutive rows of in[.][width] starting at y*nsum; 64 columns per block, 4 waves
+// take every 4th row, LDS combine (deterministic order).
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ in, float* __restrict__ out, int nrows,
+                                                          int nsum, int width, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * nsum, r1 = r0 + nsum < nrows ? r0 + nsum : nrows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < width) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) { s0 += in[(int64_t)r * width + c]; s1 += in[(int64_t)(r + 4) * width + c]; }
+    if (r < r1) s0 += in[(int64_t)r * width + c];
+  }
+  red[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < width) {
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float* o = out + (int64_t)blockIdx.y * width + c;
+    *o = accumulate ? *o + t : t;
+  }
 }
 
 }  // namespace
@@ -429,7 +464,7 @@ extern "C" int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32
 }
 
 extern "C" size_t xp_colsum_workspace_bytes(int64_t rows, int64_t cols) {
-  return (size_t)(cdiv(rows, CS_ROWS) * cols * sizeof(float));
+  return (size_t)((cdiv(rows, CS_ROWS) + 32) * cols * sizeof(float));
 }
 
 extern "C" int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* out,
@@ -440,8 +475,15 @@ extern "C" int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx,
   dim3 grid((unsigned)cdiv(cols, 256), chunks);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 64, 0, st>>>((const bf16_t*)X, rows, cols, ldx, part);
-  else                  colsum_partial_kernel<float><<<grid, 64, 0, st>>>((const float*)X, rows, cols, ldx, part);
+  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, rows, cols, ldx, part);
+  else                  colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, rows, cols, ldx, part);
   XP_CHECK_LAUNCH("xp_colsum(partial)");
-  return xp_splitk_reduce(part, out, cols, chunks, accumulate, stream);
+  // two-level deterministic reduce of the chunk partials (chunks -> <=32 -> 1): no thread walks hundreds of rows
+  const int lvl = (int)cdiv(chunks, 32), n2 = (int)cdiv(chunks, lvl);
+  float* part2 = part + (int64_t)chunks * cols;
+  rows_reduce_kernel<<<dim3((unsigned)cdiv(cols, 64), (unsigned)n2), 256, 0, st>>>(part, part2, chunks, lvl, (int)cols, 0);
+  XP_CHECK_LAUNCH("xp_colsum(reduce1)");
+  rows_reduce_kernel<<<dim3((unsigned)cdiv(cols, 64), 1), 256, 0, st>>>(part2, out, n2, n2, (int)cols, accumulate);
+  XP_CHECK_LAUNCH("xp_colsum(reduce2)");
+  return XP_OK;
 }

@@ -61,59 +61,87 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
   }
 }
 
-template <typename T>
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<bf16_t> { typedef bf16x4 type; };
+__device__ __forceinline__ f32x4 cvt4(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 cvt4(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
+template <typename T, int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* dres, int64_t lddres,
                                                      T* dx, int64_t lddx, float* __restrict__ part,
                                                      int64_t rows, int cols) {
-  __shared__ float red[WAVES][2][MAXJ * 256];
+  __shared__ float red[WAVES][2][NJ * 256];
+  typedef typename Raw4<T>::type raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nj = (cols + 255) >> 8;
-  f32x4 gm[MAXJ], dg[MAXJ], db[MAXJ];
+  f32x4 gm[NJ], dg[NJ], db[NJ];
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = j * 256 + lane * 4;
-    gm[j] = (j < nj && c < cols) ? load4(gamma + c) : f32x4{0, 0, 0, 0};
+    gm[j] = c < cols ? load4(gamma + c) : f32x4{0, 0, 0, 0};
     dg[j] = f32x4{0, 0, 0, 0}; db[j] = f32x4{0, 0, 0, 0};
   }
   const float inv = 1.0f / (float)cols;
-  for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < rows; row += (int64_t)gridDim.x * WAVES) {
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[MAXJ], gy[MAXJ];
-    float c1 = 0.f, c2 = 0.f;
+  // two rows per iteration: all loads of both rows are issued before the first reduction (memory-level parallelism);
+  // rows stay packed in their storage type until used
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const raw_t zero = __builtin_bit_cast(raw_t, typename Raw4<T>::type{});
+  for (int64_t row0 = (int64_t)blockIdx.x * WAVES + wave; row0 < rows; row0 += 2 * stride) {
+    const int64_t rws[2] = {row0, row0 + stride};
+    raw_t xr[2][NJ], dr[2][NJ], rr[2][NJ];
+    float mu[2], rs[2];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = j * 256 + lane * 4;
-      if (j < nj && c < cols) {
-        const f32x4 xv = load4(x + row * ldx + c), dv = load4(dy + row * lddy + c);
+    for (int u = 0; u < 2; ++u) {
+      const bool ok = rws[u] < rows;
+      mu[u] = ok ? mean[rws[u]] : 0.f; rs[u] = ok ? rstd[rws[u]] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (ok && c < cols) {
+          xr[u][j] = *reinterpret_cast<const raw_t*>(x + rws[u] * ldx + c);
+          dr[u][j] = *reinterpret_cast<const raw_t*>(dy + rws[u] * lddy + c);
+          rr[u][j] = dres ? *reinterpret_cast<const raw_t*>(dres + rws[u] * lddres + c) : zero;
+        } else { xr[u][j] = zero; dr[u][j] = zero; rr[u][j] = zero; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (rws[u] >= rows) continue;
+      float c1 = 0.f, c2 = 0.f;
+      f32x4 xh[NJ], gy[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4 xv = cvt4(xr[u][j]), dv = cvt4(dr[u][j]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[j][e] = (xv[e] - mu) * rs;
+          xh[j][e] = (xv[e] - mu[u]) * rs[u];
           gy[j][e] = dv[e] * gm[j][e];
           c1 += gy[j][e]; c2 += gy[j][e] * xh[j][e];
           dg[j][e] += dv[e] * xh[j][e]; db[j][e] += dv[e];
         }
-      } else { xh[j] = f32x4{0, 0, 0, 0}; gy[j] = f32x4{0, 0, 0, 0}; }
-    }
-    c1 = wave_sum(c1) * inv; c2 = wave_sum(c2) * inv;
+      }
+      // columns >= cols hold x = 0 -> xh = -mu*rs there, but gamma (hence gy) is 0 and dy is 0: they add nothing
+      c1 = wave_sum(c1) * inv; c2 = wave_sum(c2) * inv;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = j * 256 + lane * 4;
-      if (j < nj && c < cols) {
-        f32x4 o;
+      for (int j = 0; j < NJ; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < cols) {
+          const f32x4 rv = cvt4(rr[u][j]);
+          f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[j][e] - c1 - xh[j][e] * c2);
-        if (dres) o += load4(dres + row * lddres + c);
-        store4(dx + row * lddx + c, o);
+          for (int e = 0; e < 4; ++e) o[e] = rs[u] * (gy[j][e] - c1 - xh[j][e] * c2) + rv[e];
+          store4(dx + rws[u] * lddx + c, o);
+        }
       }
     }
   }
   // block-level reduce of dgamma / dbeta partials, one partial row pair per block
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = j * 256 + lane * 4;
-    if (j < nj && c < cols) { store4(&red[wave][0][c], dg[j]); store4(&red[wave][1][c], db[j]); }
+    if (c < cols) { store4(&red[wave][0][c], dg[j]); store4(&red[wave][1][c], db[j]); }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < cols; c += blockDim.x) {
@@ -125,25 +153,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   }
 }
 
-// out_g[c] (+)= sum_b part[b][0][c]; out_b[c] (+)= sum_b part[b][1][c]
-// 64 columns per block; 4 waves each sum a quarter of the partial rows (coalesced 256-byte reads), LDS combine.
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta,
-                                                              int nblocks, int cols, int accumulate) {
+// Sum `nsum` consecutive partial rows (each 2*cols wide: dgamma | dbeta) per blockIdx.y; 64 columns per block,
+// 4 waves take every 4th row (coalesced 256-byte reads, 4 loads in flight), LDS combine.  Called twice
+// (1024 -> 32 -> 1 rows) so no thread walks more than 8 rows and the sum order is fixed (deterministic).
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ in, float* __restrict__ out, int nrows,
+                                                              int nsum, int width, int accumulate) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;                 // index into the concatenated [2*cols] (gamma | beta)
-  float s = 0.f;
-  if (c < 2 * cols) {
-    const int which = c / cols, col = c % cols;
-    for (int b = w; b < nblocks; b += 4) s += part[((int64_t)b * 2 + which) * cols + col];
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * nsum, r1 = r0 + nsum < nrows ? r0 + nsum : nrows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < width) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) { s0 += in[(int64_t)r * width + c]; s1 += in[(int64_t)(r + 4) * width + c]; }
+    if (r < r1) s0 += in[(int64_t)r * width + c];
   }
+  red[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < width) {
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float* o = out + (int64_t)blockIdx.y * width + c;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_param_reduce2_kernel(const float* __restrict__ in, float* dgamma, float* dbeta,
+                                                               int nrows, int cols, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, width = 2 * cols;
+  float s = 0.f;
+  if (c < width)
+    for (int r = w; r < nrows; r += 4) s += in[(int64_t)r * width + c];
   red[w][lane] = s;
   __syncthreads();
-  if (w == 0 && c < 2 * cols) {
+  if (w == 0 && c < width) {
     const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    const int which = c / cols, col = c % cols;
-    float* out = which ? dbeta : dgamma;
-    out[col] = accumulate ? out[col] + t : t;
+    float* o = c < cols ? dgamma + c : dbeta + (c - cols);
+    *o = accumulate ? *o + t : t;
   }
 }
 
@@ -170,7 +217,7 @@ extern "C" int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
 }
 
 extern "C" size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
-  return (size_t)bwd_blocks(rows) * 2 * cols * sizeof(float);
+  return (size_t)(bwd_blocks(rows) + 32) * 2 * cols * sizeof(float);
 }
 
 extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
@@ -185,15 +232,24 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
   const int blocks = bwd_blocks(rows);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  if (dtype == XP_BF16)
-    ln_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, gamma, mean, rstd,
-                                                  (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, part, rows, (int)cols);
-  else if (dtype == XP_F32)
-    ln_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)dy, lddy, (const float*)x, ldx, gamma, mean, rstd,
-                                                 (const float*)dres, lddres, (float*)dx, lddx, part, rows, (int)cols);
-  else XP_REQUIRE(false, "xp_layernorm_bwd: bad dtype %d", dtype);
+  XP_REQUIRE(dtype == XP_BF16 || dtype == XP_F32, "xp_layernorm_bwd: bad dtype %d", dtype);
+  const int nj = (int)cdiv(cols, 256);
+#define XP_LN_BWD(T, NJ)                                                                                             \
+  ln_bwd_kernel<T, NJ><<<blocks, 256, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, gamma, mean, rstd, (const T*)dres, \
+                                               lddres, (T*)dx, lddx, part, rows, (int)cols)
+  if (dtype == XP_BF16) { if (nj == 1) XP_LN_BWD(bf16_t, 1); else if (nj == 2) XP_LN_BWD(bf16_t, 2); else if (nj == 3) XP_LN_BWD(bf16_t, 3); else XP_LN_BWD(bf16_t, 4); }
+  else                  { if (nj == 1) XP_LN_BWD(float, 1);  else if (nj == 2) XP_LN_BWD(float, 2);  else if (nj == 3) XP_LN_BWD(float, 3);  else XP_LN_BWD(float, 4); }
+#undef XP_LN_BWD
   XP_CHECK_LAUNCH("xp_layernorm_bwd");
-  ln_param_reduce_kernel<<<(unsigned)cdiv(2 * cols, 64), 256, 0, st>>>(part, dgamma, dbeta, blocks, (int)cols, accumulate);
-  XP_CHECK_LAUNCH("xp_layernorm_bwd(reduce)");
+  // two-level deterministic reduce of the per-block partial rows: blocks -> <=32 -> 1; dgamma/dbeta may be two
+  // separate buffers, so the last level runs once per output
+  const int width = 2 * (int)cols, lvl = (int)cdiv(blocks, 32);
+  float* part2 = part + (int64_t)blocks * width;
+  ln_param_reduce_kernel<<<dim3((unsigned)cdiv(width, 64), (unsigned)cdiv(blocks, lvl)), 256, 0, st>>>(part, part2, blocks, lvl, width, 0);
+  XP_CHECK_LAUNCH("xp_layernorm_bwd(reduce1)");
+  const int n2 = (int)cdiv(blocks, lvl);
+  // level 2 on the gamma half and the beta half (row stride = width)
+  ln_param_reduce2_kernel<<<(unsigned)cdiv(width, 64), 256, 0, st>>>(part2, dgamma, dbeta, n2, (int)cols, accumulate);
+  XP_CHECK_LAUNCH("xp_layernorm_bwd(reduce2)");
   return XP_OK;
 }

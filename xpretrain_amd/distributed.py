@@ -7,9 +7,9 @@ utils/distributed.py) with three pieces designed for point-to-point xGMI rather 
   incoming gradient and issues no collective: every rank computes the same loss from bit-identical gathered
   inputs, so Horovod's averaged all-reduce in allgather-backward is a numerical no-op (SURVEY.md §5/§8e;
   ``verify_identical=True`` runs the real all-reduce and asserts that).
-* ``GradBucketReducer`` -- parameters' ``.grad`` are views into a few large flat fp32 buckets (layer-reverse
-  order, ~64 MB each: few, big messages that keep all 7 xGMI links busy); a bucket's all-reduce is launched
-  asynchronously from the autograd hook of its last gradient, overlapping the rest of backward.
+* ``GradBucketReducer`` -- a few large flat fp32 buckets (layer-reverse order, ~64 MB each: few, big messages that
+  keep all 7 xGMI links busy); when a bucket's last gradient arrives its gradients are packed with one
+  multi-tensor copy and the all-reduce is launched asynchronously, overlapping the rest of backward.
   ``average=True`` reproduces ``hvd.DistributedOptimizer`` (grads / world_size).
 * ``broadcast_parameters`` -- rank-0 -> all at start-up (hvd.broadcast_parameters, run_pretrain.py:231).
 
@@ -90,7 +90,13 @@ def gather_features(vis: torch.Tensor, txt: torch.Tensor, verify_identical: bool
 
 
 class GradBucketReducer:
-    """Bucketed, backward-overlapped gradient all-reduce (the role of hvd.DistributedOptimizer + synchronize())."""
+    """Bucketed, backward-overlapped gradient all-reduce (the role of hvd.DistributedOptimizer + synchronize()).
+
+    Gradients start each step as ``None``: autograd then *adopts* the tensors our backward kernels return (no
+    per-parameter ``grad += new`` kernels, no zero-fill of 600 MB of gradient memory).  When the last gradient of
+    a bucket arrives (autograd hook), the bucket's gradients are packed into its flat fp32 buffer with ONE
+    multi-tensor copy, ``.grad`` is re-pointed at the flat views, and the bucket's all-reduce is launched
+    asynchronously -- overlapping the rest of backward.  With world_size 1 nothing is copied at all."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, average: bool = True,
                  group=None):
@@ -99,6 +105,7 @@ class GradBucketReducer:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.buckets = []
         self._bucket_of = {}
+        self._active = world_size() > 1
         cap = int(bucket_mb * (1 << 20)) // 4
         cur, cur_n = [], 0
         for p in reversed(self.params):        # gradients become ready roughly in reverse parameter order
@@ -109,56 +116,67 @@ class GradBucketReducer:
             cur_n += p.numel()
         if cur:
             self._make_bucket(cur)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self._active else []
 
     def _make_bucket(self, ps):
-        n = sum(p.numel() for p in ps)
-        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
-        b = dict(flat=flat, params=list(ps), views={}, ready=0, work=None)
-        off = 0
+        b = dict(flat=None, params=list(ps), views=None, ready=0, work=None, n=sum(p.numel() for p in ps))
         for p in ps:
-            v = flat[off:off + p.numel()].view_as(p)
-            b["views"][id(p)] = v
-            p.grad = v
             self._bucket_of[id(p)] = b
-            off += p.numel()
         self.buckets.append(b)
 
+    def _ensure_flat(self, b):
+        if b["flat"] is None:
+            flat = torch.empty(b["n"], dtype=torch.float32, device=b["params"][0].device)
+            views, off = [], 0
+            for p in b["params"]:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            b["flat"], b["views"] = flat, views
+
     def _launch(self, b):
-        if world_size() > 1:
-            b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+        """pack the bucket (one multi-tensor copy; parameters without a gradient contribute zeros) and all-reduce."""
+        self._ensure_flat(b)
+        src, dst = [], []
+        for p, v in zip(b["params"], b["views"]):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad if p.grad.dtype == torch.float32 else p.grad.float())
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(b["params"], b["views"]):
+            p.grad = v
+        b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
-        v = b["views"][id(p)]
-        if p.grad is not v:                    # someone replaced .grad (zero_grad(set_to_none=True)): re-home it
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-            p.grad = v
         b["ready"] += 1
-        if b["ready"] == len(b["params"]):
+        if b["ready"] == len(b["params"]) and b["work"] is None:
             self._launch(b)
 
     def synchronize(self):
-        """Wait for every bucket (launching those whose parameters got no gradient this step) and average."""
+        """Wait for every bucket (launching those whose parameters did not all receive a gradient) and average."""
+        if not self._active:
+            return
         W = world_size()
         for b in self.buckets:
-            if b["work"] is None and W > 1 and b["ready"] < len(b["params"]):
+            if b["work"] is None:
                 self._launch(b)
         for b in self.buckets:
-            if b["work"] is not None:
-                b["work"].wait()
-                b["work"] = None
-            if self.average and W > 1:
+            b["work"].wait()
+            b["work"] = None
+            if self.average:
                 b["flat"].div_(W)
             b["ready"] = 0
 
     def zero_grad(self):
-        """Use instead of optimizer.zero_grad(): keeps ``.grad`` pointing into the flat buckets."""
+        """Use instead of optimizer.zero_grad(): gradients go back to ``None`` so the next backward's tensors are
+        adopted without an accumulate kernel."""
+        for p in self.params:
+            p.grad = None
         for b in self.buckets:
-            b["flat"].zero_()
-            for p in b["params"]:
-                p.grad = b["views"][id(p)]
+            b["ready"] = 0
 
     def remove(self):
         for h in self._hooks:
