@@ -47,7 +47,8 @@ def bench_gemm():
         us = timeit(lambda: H.gemm(dY, W, M, K, N, b_kstrided=True, out=dX))
         print(f"gemm dX  {name:4s}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
         # dW[N,K] = dY^T X, split-K
-        for split in (4, 8, 16):
+        import os
+        for split in ((7, 9, 14, 28) if os.environ.get('XPRETRAIN_GEMM256_SPLITK') else (4, 8, 16)):
             slabs = torch.empty(split, N, K, device="cuda")
             dW = torch.empty(N, K, device="cuda")
             def f():

@@ -236,13 +236,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   }
   __syncthreads();
 
+  // optional trace: wave 0 of the middle workgroup stamps s_memtime at 5 points of each of its first 24 k-iterations
+  const bool trace = p.dbg != nullptr && (int)blockIdx.x == nwg / 2 && blockIdx.z == 0 && wave == 0;
+  unsigned long long* tr = p.dbg;
+#define XP_STAMP(i) do { if (trace && kt < 24) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) tr[8 + kt * 5 + (i)] = t_; } } while (0)
+  if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
   for (int kt = 0; kt < nk; ++kt) {
     const int s = kt & 1;
+    XP_STAMP(0);
     if constexpr (GLDS) {
       if (kt + 1 < nk) { ga.issue(sA(s ^ 1), kt + 1); gb.issue(sB(s ^ 1), kt + 1); }
     } else {
       if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * KE);
     }
+    XP_STAMP(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       typename Frag<T>::type fw[4], fx[4];
@@ -255,13 +262,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
     }
+    XP_STAMP(2);
     if constexpr (GLDS) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       if (kt + 1 < nk) lstore(s ^ 1);
     }
+    XP_STAMP(3);
     __syncthreads();
+    XP_STAMP(4);
   }
+  if (trace && lane == 0) tr[2] = __builtin_amdgcn_s_memtime();
+#undef XP_STAMP
 
   // ---- epilogue ---------------------------------------------------------------------------------------
   // The accumulator lane owns 4 consecutive n of ONE row, i.e. a wave store would touch 16 rows x 32 B.  Instead
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((c ^ (row & 7)) << 4));
     epi_row<T>(p, el, v, m, n, Cf, Ct);
   }
+  if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
 }
 
 template <typename T, bool GLDS>
@@ -401,6 +414,9 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
 
 }  // namespace
 
+static unsigned long long* g_gemm_trace = nullptr;
+extern "C" int xp_debug_set_gemm_trace(void* device_buffer) { g_gemm_trace = (unsigned long long*)device_buffer; return XP_OK; }
+
 extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   XP_REQUIRE(d && d->A && d->B && d->C, "xp_gemm: null operand");
   XP_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "xp_gemm: empty problem M=%lld N=%lld K=%lld",
@@ -437,6 +453,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.bias = d->bias; kp.scale = d->scale; kp.scale_cols = d->scale_cols;
   kp.resid = d->resid; kp.ldr = d->ldr; kp.aux = d->aux; kp.ldaux = d->ldaux;
   kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
+  kp.dbg = g_gemm_trace;
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
   const int zsplits = (int)cdiv(d->K, kp.k_per_split);
   XP_REQUIRE(split == 1 || zsplits == split, "xp_gemm: split_k=%d leaves empty slabs for K=%lld (use <= %d)",

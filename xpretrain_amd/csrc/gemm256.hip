@@ -1,21 +1,24 @@
-// 256x128-tile, deep-pipelined MFMA GEMM for the large [tokens x features] contractions of the path.
+// 256x256-tile MFMA GEMM (experimental second family; OFF by default, XPRETRAIN_GEMM256=1|2 enables it).
 //
-// Why a second family (measured on MI355X, profiles/r01*): the 128x128 kernel spends 43 % of its wave-cycles
-// parked at s_waitcnt/s_barrier -- with two LDS stages each stage's DMA has only one stage of MFMA work
-// (0.2-0.4 us) to hide 0.5-0.9 us of L2/HBM latency, and a K=768 problem is only 12 stages long.  This kernel keeps
-// TWO further stages of direct-to-LDS DMA in flight across barriers (counted vmcnt, raw s_barrier) and uses a
-// 256-row M tile (1.33x fewer L2->LDS bytes per FLOP):
+// Motivation (measured on MI355X with tools/gemm_trace.py, s_memtime stamps inside the 128x128 kernel): one k-iteration
+// of the production kernel costs 2200-3000 cycles per wave for 544 cycles of MFMA work -- ~700-1100 cycles ISSUING its
+// eight 1-KiB buffer_load...lds pieces (the CU's texture-address path moves 64 B/clk, and a 128x128x64 stage needs 32 KiB
+// per 544 MFMA-cycles, i.e. the TA is ~94 % as busy as the matrix pipe), ~320-600 cycles waiting for the DMA and ~330 at
+// the barrier.  A 256x256 tile halves the bytes that cross the TA per FLOP.
 //
-//   workgroup  512 threads = 8 waves as 4 (M) x 2 (N); wave tile 64 x 64 = 4 x 4 accumulators
-//   stage      128 BYTES of k (64 bf16 / 32 f32): A 256 rows (32 KiB) + B 128 rows (16 KiB); ring of NS = 3 = 144 KiB
-//              (128-byte rows: a 64-byte-row variant measured 0.7x -- half-line L1 fills double the L2->L1 traffic)
-//   per stage  s_waitcnt vmcnt(6 * stages that may stay in flight) ; raw s_barrier ; issue stage t+2 ;
-//              2 x (8 fragment reads + 16 MFMA) per wave.  ONE barrier per stage, never vmcnt(0) in steady state.
-//   ordering   RAW: a wave waits for its own DMA of stage t (counted vmcnt), then the barrier -> every wave's DMA of
-//              stage t has landed before anyone reads it.  WAR: slot (t-1)%3 is refilled only after the barrier of
-//              iteration t, which every wave reaches after finishing its reads of stage t-1.
-//   epilogue   wave-private 8 KiB LDS staging (2 rounds of 32 rows x 64 cols fp32), row-major read-back, shared
-//              fused epilogue (gemm_common.h) -> full-line coalesced loads/stores.
+//   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 accumulators (128 VGPRs)
+//   stage      128 BYTES of k (64 bf16 / 32 f32), 256 + 256 rows = 64 KiB; 2 stages = 128 KiB LDS, 1 workgroup / CU
+//              (64-byte-row stages measured 0.7x: half-line L1 fills double the L2->L1 traffic)
+//   per stage  s_waitcnt vmcnt(0) ; raw s_barrier ; issue stage t+1 ; 2 x (12 fragment reads + 32 MFMA) per wave
+//   epilogue   wave-private LDS staging (rounds of 32 rows x 64 cols fp32), row-major read-back, shared fused epilogue
+//
+// Results at BASELINE cfg #2 shapes (gpurun_out/call18, call19): best steady state of all variants (K=3072 forward
+// 903 TFLOP/s vs 871 for 128x128) but WORSE on the K=768 problems (430-490 vs 490-680 TFLOP/s): only 222-888 tiles for
+// 256 CUs at one workgroup per CU, so the prologue latency, the 12-stage loop and the large epilogue are fully
+// exposed.  Variants tried on the way, all correct and all <= the 128x128 family here: 64-byte-row 4-stage ring;
+// 256x128 3-stage ring with counted vmcnt; the same with two wave groups staggered by half a sub-step.
+// Next step (not built): persistent tile loop (prefetch the next tile's first stage under the epilogue) + producer
+// wave so the MFMA waves never pay the DMA issue cost.
 //
 // Tile images are the 128x128 family's (gemm.hip) with more rows; XOR swizzles are applied to the per-lane GLOBAL
 // source address of the lane-linear DMA:
@@ -30,8 +33,9 @@ namespace {
 
 using namespace xpgemm;
 
-constexpr int TM = 256, TN = 128, SKB = 128;     // SKB: bytes of k per stage
-constexpr int NTH = 512, NWAVES = 8, NS = 3;
+constexpr int TM = 256, TN = 256, SKB = 128;     // SKB: bytes of k per stage
+constexpr int NTH = 512, NWAVES = 8, NS = 2;
+constexpr int WAVES_N = 4, MT = TM / (NWAVES / WAVES_N) / 16, NT = TN / WAVES_N / 16;   // wave tile 128 x 64: 8 x 4
 constexpr int A_BYTES = TM * SKB, B_BYTES = TN * SKB;
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KiB
 constexpr int LPS = (A_BYTES + B_BYTES) / (NTH * 16);   // DMA instructions per thread per stage = 6
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = xcd_remap(blockIdx.x, nwg);
@@ -140,11 +144,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   auto slotA = [&](int s) -> char* { return smem + s * STAGE_BYTES; };
   auto slotB = [&](int s) -> char* { return smem + s * STAGE_BYTES + A_BYTES; };
 
-  f32x4 acc[4][4];
+  f32x4 acc[NT][MT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // prologue: NS-1 stages in flight
 #pragma unroll
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   int slot = 0;
   for (int t = 0; t < nk; ++t) {
     // stages issued so far = min(nk, t+NS-1); stage t must have landed -> the younger one may stay in flight
-    if (t + 1 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+    if (NS > 2 && t + 1 < nk) wait_vmcnt<(NS - 2) * LPS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (t + NS - 1 < nk) {
       const int s2 = slot == 0 ? NS - 1 : slot - 1;          // (t + NS - 1) % NS == (t - 1) % NS
@@ -165,46 +169,48 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     const char* tB = slotB(slot);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      typename Frag<T>::type fw[4], fx[4];
+      typename Frag<T>::type fw[NT], fx[MT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fw[i] = frag<T, BKS, TN>(tB, wn * 4 + i, ks, lane);
+      for (int i = 0; i < NT; ++i) fw[i] = frag<T, BKS, TN>(tB, wn * NT + i, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fx[i] = frag<T, AKS, TM>(tA, wm * 4 + i, ks, lane);
+      for (int i = 0; i < MT; ++i) fx[i] = frag<T, AKS, TM>(tA, wm * MT + i, ks, lane);
+      __builtin_amdgcn_sched_barrier(0);      // all fragment reads in flight before the first MFMA (no read/wait/MFMA ping-pong)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
     }
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();        // every wave is done reading the ring -> LDS is free for the epilogue
 
-  // ---- epilogue: wave-private staging, 2 rounds of 32 rows x 64 columns ------------------------------
-  char* stg = smem + wave * 8192;
+  // ---- epilogue: wave-private staging, MT/2 rounds of 32 rows x (NT*16) columns --------------------------------
+  constexpr int CW = NT * 16, CCH = CW / 4;                 // staged columns per wave, 16-byte chunks per row
+  char* stg = smem + wave * (32 * CW * 4);
   const int i16 = lane & 15, g = lane >> 4;
-  const int c = lane & 15, r4 = lane >> 4;
-  const int64_t n = n0 + wn * 64 + c * 4;
+  const int c = lane % CCH, r4 = lane / CCH;                // read-back: CCH lanes per row, 64/CCH rows per pass
+  const int64_t n = n0 + wn * CW + c * 4;
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
   const bool ncol_ok = n < p.N;
   const EpiLane el(p, ncol_ok ? n : 0);
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < MT / 2; ++q) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = h * 16 + i16;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        *reinterpret_cast<f32x4*>(stg + row * 256 + (((nt * 4 + g) ^ (row & 7)) << 4)) = acc[nt][q * 2 + h];
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(stg + row * (CW * 4) + (((nt * 4 + g) ^ (row & 7)) << 4)) = acc[nt][q * 2 + h];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int row = pass * 4 + r4;
-      const int64_t m = m0 + wm * 64 + q * 32 + row;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 256 + ((c ^ (row & 7)) << 4));
+    for (int pass = 0; pass < 32 / (64 / CCH); ++pass) {
+      const int row = pass * (64 / CCH) + r4;
+      const int64_t m = m0 + wm * (MT * 16) + q * 32 + row;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + ((c ^ (row & 7)) << 4));
       if (ncol_ok && m < p.M) epi_row<T>(p, el, v, m, n, Cf, Ct);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -243,10 +249,7 @@ XP_INST(float)
 }  // namespace
 
 bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st) {
-  // 0 = off (default), 1 = size heuristic, 2 = whenever legal.  Measured on MI355X (gpurun call 11): correct, but at
-  // cfg #2 shapes 0.8-0.9x the 128x128 family -- eight lock-stepped waves behind one barrier lose more than the
-  // deeper DMA ring wins over two independent 4-wave workgroups per CU.  Kept (tested) as the base for a
-  // wave-specialised schedule; not on the default path.
+  // 0 = off (default), 1 = size heuristic, 2 = whenever legal (see the header comment for the measurements).
   const char* env = getenv("XPRETRAIN_GEMM256");
   const int mode = env ? atoi(env) : 0;
   if (mode == 0) return false;

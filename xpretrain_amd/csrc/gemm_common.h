@@ -22,6 +22,7 @@ struct KParams {
   void* aux; int64_t ldaux;
   const float* tab1; const float* tab2; int64_t tab_L;
   int tiles_m, tiles_n;
+  unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
 
 
