@@ -87,6 +87,27 @@ __device__ __forceinline__ void load_tile_o(char* tile, const bf16_t* src, const
     *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = v;
   }
 }
+// ---- split tile load (software pipelining): global -> registers is issued one tile AHEAD, under the MFMA work of the
+// current tile; registers -> LDS happens after the barrier that frees the tile.  One exposed global round trip per
+// workgroup instead of one per 64-row tile.
+__device__ __forceinline__ void gload_tile(u32x4 (&v)[2], const bf16_t* src, int64_t ld, int64_t col0, const AP& p,
+                                           const Prob& pr, int row0, int tid) {
+  const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = row0 + rr + 32 * j;
+    v[j] = u32x4{0, 0, 0, 0};
+    if (r < p.R) {
+      const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
+      v[j] = *reinterpret_cast<const u32x4*>(src + t * ld + col0 + c * 8);
+    }
+  }
+}
+__device__ __forceinline__ void lstore_tile(char* tile, const u32x4 (&v)[2], int tid) {
+  const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(tile + tile128_off(rr + 32 * j, c)) = v[j];
+}
 // per-lane register fragment of one row (as MFMA B operand: lane (j = row, g) holds d = 32kk + 8g .. +8)
 __device__ __forceinline__ void load_row_frag(bf16x8 (&f)[2], const bf16_t* rowptr, bool valid, int g) {
 #pragma unroll
@@ -142,15 +163,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AP p) {
   int ntiles = (p.R + 63) / 64;
   if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
 
+  u32x4 rK[2], rV[2];
+  unsigned char rPad = 0;
+  const int64_t kcol = (int64_t)p.H * DH + pr.h * DH, vcol = (int64_t)2 * p.H * DH + pr.h * DH;
+  auto prefetch = [&](int kt) {
+    gload_tile(rK, p.qkv, p.ldqkv, kcol, p, pr, kt * 64, tid);
+    gload_tile(rV, p.qkv, p.ldqkv, vcol, p, pr, kt * 64, tid);
+    const int r = kt * 64 + (tid & 63);
+    rPad = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
+  };
+  if (ntiles > 0) prefetch(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * 64;
-    load_tile_qkv(sK, p, pr, 1, kb, tid);
-    load_tile_qkv(sV, p, pr, 2, kb, tid);
-    if (tid < 64) {
-      const int r = kb + tid;
-      sPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
-    }
+    lstore_tile(sK, rK, tid);
+    lstore_tile(sV, rV, tid);
+    if (tid < 64) sPad[tid] = rPad;
     __syncthreads();
+    if (kt + 1 < ntiles) prefetch(kt + 1);
 
     f32x4 s[4];
 #pragma unroll
@@ -272,20 +301,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
 
   const int ntiles = (p.R + 63) / 64;
   const int qt0 = p.mode == XP_ATTN_CAUSAL ? kb / 64 : 0;     // queries before the first key never see it
+  u32x4 rQ[2], rDO[2];
+  float rM = 0.f, rLg = 0.f, rDl = 0.f;
+  auto prefetch = [&](int qt) {
+    gload_tile(rQ, p.qkv, p.ldqkv, (int64_t)pr.h * DH, p, pr, qt * 64, tid);
+    gload_tile(rDO, p.dout, p.ldo, (int64_t)pr.h * DH, p, pr, qt * 64, tid);
+    const int r = qt * 64 + (tid & 63);
+    rM = 0.f; rLg = 0.f; rDl = 0.f;
+    if (tid < 64 && r < p.R) {
+      const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
+      rM = p.stats[si * 2]; rLg = p.stats[si * 2 + 1]; rDl = p.ws0[si];
+    }
+  };
+  if (qt0 < ntiles) prefetch(qt0);
   for (int qt = qt0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
-    load_tile_qkv(sQ, p, pr, 0, qb, tid);
-    load_tile_o(sDO, p.dout, p, pr, qb, tid);
-    if (tid < 64) {
-      const int r = qb + tid;
-      float mm = 0.f, lg = 0.f, dl = 0.f;
-      if (r < p.R) {
-        const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
-        mm = p.stats[si * 2]; lg = p.stats[si * 2 + 1]; dl = p.ws0[si];
-      }
-      sM[tid] = mm; sLg[tid] = lg; sDl[tid] = dl;
-    }
+    lstore_tile(sQ, rQ, tid);
+    lstore_tile(sDO, rDO, tid);
+    if (tid < 64) { sM[tid] = rM; sLg[tid] = rLg; sDl[tid] = rDl; }
     __syncthreads();
+    if (qt + 1 < ntiles) prefetch(qt + 1);
 
     f32x4 pp[4], ds[4];
 #pragma unroll
@@ -359,15 +394,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AP p) {
 
   int ntiles = (p.R + 63) / 64;
   if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
+  u32x4 rK[2], rV[2];
+  unsigned char rPad = 0;
+  const int64_t kcol = (int64_t)p.H * DH + pr.h * DH, vcol = (int64_t)2 * p.H * DH + pr.h * DH;
+  auto prefetch = [&](int kt) {
+    gload_tile(rK, p.qkv, p.ldqkv, kcol, p, pr, kt * 64, tid);
+    gload_tile(rV, p.qkv, p.ldqkv, vcol, p, pr, kt * 64, tid);
+    const int r = kt * 64 + (tid & 63);
+    rPad = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
+  };
+  if (ntiles > 0) prefetch(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * 64;
-    load_tile_qkv(sK, p, pr, 1, kb, tid);
-    load_tile_qkv(sV, p, pr, 2, kb, tid);
-    if (tid < 64) {
-      const int r = kb + tid;
-      sPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
-    }
+    lstore_tile(sK, rK, tid);
+    lstore_tile(sV, rV, tid);
+    if (tid < 64) sPad[tid] = rPad;
     __syncthreads();
+    if (kt + 1 < ntiles) prefetch(kt + 1);
     f32x4 ds[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
