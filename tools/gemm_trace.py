@@ -23,7 +23,9 @@ for name, N, K in [("fc1", 3072, 768), ("fc2", 768, 3072)]:
     t = buf.cpu().tolist()
     nk = t[1]
     print(f"== {name}: nk={nk} loop={t[2]-t[0]} cyc epilogue={t[3]-t[2]} cyc  (s_memtime ticks; 100 MHz ref clock if constant)")
-    print(" kt   issue  compute  vmwait  barrier   total")
+    import os
+    g256 = os.environ.get("XPRETRAIN_GEMM256", "0") != "0"
+    print(" kt  vmwait  barrier   issue  compute   total" if g256 else " kt   issue  compute  vmwait  barrier   total")
     prev = None
     for kt in range(min(nk, 24)):
         s = t[8 + kt * 5: 8 + kt * 5 + 5]

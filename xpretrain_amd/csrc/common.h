@@ -58,6 +58,20 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// 8 consecutive elements <-> two f32x4 (16-byte bf16 / 2 x 16-byte f32 accesses)
+struct f32x8 { f32x4 lo, hi; };
+__device__ __forceinline__ f32x8 load8(const float* p) { return f32x8{load4(p), load4(p + 4)}; }
+__device__ __forceinline__ f32x8 load8(const bf16_t* p) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  return f32x8{f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
+}
+__device__ __forceinline__ void store8(float* p, f32x8 v) { store4(p, v.lo); store4(p + 4, v.hi); }
+__device__ __forceinline__ void store8(bf16_t* p, f32x8 v) {
+  bf16x8 o = {(bf16_t)v.lo[0], (bf16_t)v.lo[1], (bf16_t)v.lo[2], (bf16_t)v.lo[3],
+              (bf16_t)v.hi[0], (bf16_t)v.hi[1], (bf16_t)v.hi[2], (bf16_t)v.hi[3]};
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
   float s = 1.0f / (1.0f + __expf(-1.702f * x));

@@ -294,13 +294,31 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   }
   __syncthreads();
 
-  const int ep = p.epilogue;
-  const int c = tid & 31, r8 = tid >> 5;
-  const int64_t n = n0 + c * 4;
-  if (n >= p.N) return;
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
+  if (p.wide) {          // 8 columns per lane: 16 lanes cover a row, 16 rows per pass, 16-byte bf16 stores
+    const int c8 = tid & 15, r16 = tid >> 4;
+    const int64_t n8 = n0 + c8 * 8;
+    if (n8 < p.N) {
+      const EpiLane8 el8(p, n8);
+#pragma unroll 4
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 16 + r16;
+        const int64_t m = m0 + row;
+        if (m >= p.M) break;
+        const char* rp = smem + row * 512;
+        const f32x8 v = {*reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ (row & 7)) << 4)),
+                         *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ (row & 7)) << 4))};
+        epi_row8<T>(p, el8, v, m, n8, Cf, Ct);
+      }
+    }
+    if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
+    return;
+  }
+  const int c = tid & 31, r8 = tid >> 5;
+  const int64_t n = n0 + c * 4;
+  if (n >= p.N) return;
   const EpiLane el(p, n);
 
 #pragma unroll 4
@@ -454,6 +472,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.resid = d->resid; kp.ldr = d->ldr; kp.aux = d->aux; kp.ldaux = d->ldaux;
   kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
   kp.dbg = g_gemm_trace;
+  kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
   const int zsplits = (int)cdiv(d->K, kp.k_per_split);
   XP_REQUIRE(split == 1 || zsplits == split, "xp_gemm: split_k=%d leaves empty slabs for K=%lld (use <= %d)",

@@ -150,6 +150,10 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const bool trace = p.dbg != nullptr && (int)blockIdx.x == nwg / 2 && blockIdx.z == 0 && wave == 0;
+  unsigned long long* tr = p.dbg;
+#define XP_STAMP(i) do { if (trace && t < 24) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) tr[8 + t * 5 + (i)] = t_; } } while (0)
+  if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
   // prologue: NS-1 stages in flight
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
@@ -157,14 +161,18 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 
   int slot = 0;
   for (int t = 0; t < nk; ++t) {
+    XP_STAMP(0);
     // stages issued so far = min(nk, t+NS-1); stage t must have landed -> the younger one may stay in flight
     if (NS > 2 && t + 1 < nk) wait_vmcnt<(NS - 2) * LPS>(); else wait_vmcnt<0>();
+    XP_STAMP(1);
     __builtin_amdgcn_s_barrier();
+    XP_STAMP(2);
     if (t + NS - 1 < nk) {
       const int s2 = slot == 0 ? NS - 1 : slot - 1;          // (t + NS - 1) % NS == (t - 1) % NS
       ga.issue(slotA(s2), t + NS - 1);
       gb.issue(slotB(s2), t + NS - 1);
     }
+    XP_STAMP(3);
     const char* tA = slotA(slot);
     const char* tB = slotB(slot);
 #pragma unroll
@@ -180,10 +188,13 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
     }
+    XP_STAMP(4);
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
+#undef XP_STAMP
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();        // every wave is done reading the ring -> LDS is free for the epilogue
+  if (trace && lane == 0) tr[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: wave-private staging, MT/2 rounds of 32 rows x (NT*16) columns --------------------------------
   constexpr int CW = NT * 16, CCH = CW / 4;                 // staged columns per wave, 16-byte chunks per row
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
 }
 
 template <typename T, bool AKS, bool BKS>

@@ -22,6 +22,7 @@ struct KParams {
   void* aux; int64_t ldaux;
   const float* tab1; const float* tab2; int64_t tab_L;
   int tiles_m, tiles_n;
+  int wide;                  // 1: N, ldc, ldr, ldaux all multiples of 8 -> 8 columns per lane, 16-byte bf16 stores
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
 
@@ -61,6 +62,40 @@ __device__ __forceinline__ void epi_row(const KParams& p, const EpiLane& el, f32
   }
   if (p.out_f32) store4(Cf + crow * p.ldc + n, v);
   else           store4(Ct + crow * p.ldc + n, v);
+}
+
+// 8-column variant: half as many (16-byte) store instructions -- the epilogue is store-ISSUE bound.
+struct EpiLane8 {
+  f32x8 bias; float cs_lo, cs_hi;
+  __device__ __forceinline__ EpiLane8(const KParams& p, int64_t n) {
+    const EpiLane a(p, n), b(p, n + 4);
+    bias = f32x8{a.bias, b.bias}; cs_lo = a.colscale; cs_hi = b.colscale;
+  }
+};
+template <typename T>
+__device__ __forceinline__ void epi_row8(const KParams& p, const EpiLane8& el, f32x8 v, int64_t m, int64_t n, float* Cf, T* Ct) {
+  const int ep = p.epilogue;
+  v.lo = (v.lo + el.bias.lo) * el.cs_lo; v.hi = (v.hi + el.bias.hi) * el.cs_hi;
+  const int64_t crow = p.cmap(m);
+  if (ep == XP_EPI_BIAS_GELU) {
+    if (p.out_f32) store8(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
+    else           store8(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
+  } else if (ep == XP_EPI_BIAS_RESID) {
+    const f32x8 r = load8(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+    v.lo += r.lo; v.hi += r.hi;
+  } else if (ep == XP_EPI_GELU_BWD) {
+    const f32x8 pre = load8(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v.lo[e] *= quick_gelu_grad_f(pre.lo[e]); v.hi[e] *= quick_gelu_grad_f(pre.hi[e]); }
+  } else if (ep == XP_EPI_PATCH) {
+    const int64_t w = p.cmap.grp ? (m % p.cmap.grp) : m;
+    const f32x8 a = load8(p.tab1 + (w / p.tab_L) * p.N + n), b = load8(p.tab2 + (w % p.tab_L) * p.N + n);
+    v.lo += a.lo + b.lo; v.hi += a.hi + b.hi;
+  }
+  if (p.out_f32) store8(Cf + crow * p.ldc + n, v);
+  else           store8(Ct + crow * p.ldc + n, v);
 }
 
 __device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
