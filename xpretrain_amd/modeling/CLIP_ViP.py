@@ -429,12 +429,44 @@ class CLIPModel(CLIPPreTrainedModel):
 
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, return_loss=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None):
+        # The text tower is ~250 rows: its ~700 kernels per step are launch-latency bound and occupy a few CUs each.
+        # Run it (whole tower incl. its projection) on a side HIP stream so it overlaps the video tower's large
+        # GEMMs; autograd replays each backward op on its forward stream, so the text backward overlaps too.
+        side = self._text_stream(pixel_values.device) if (self.overlap_text_tower and pixel_values is not None
+                                                           and pixel_values.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_outputs = self.text_model(input_ids=input_ids, attention_mask=attention_mask,
+                                               position_ids=position_ids, output_attentions=output_attentions,
+                                               output_hidden_states=output_hidden_states)
+                text_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(text_outputs["pooler_output"], self.text_projection.weight))
+            vision_outputs = self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
+                                               output_hidden_states=output_hidden_states)
+            image_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(vision_outputs["pooler_output"], self.visual_projection.weight))
+            main.wait_stream(side)
+            text_embeds.record_stream(main)
+            return self._finish(image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict,
+                                output_hidden_states)
         vision_outputs = self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
                                            output_hidden_states=output_hidden_states)
         text_outputs = self.text_model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                        output_attentions=output_attentions, output_hidden_states=output_hidden_states)
         image_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(vision_outputs["pooler_output"], self.visual_projection.weight))
         text_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(text_outputs["pooler_output"], self.text_projection.weight))
+        return self._finish(image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict,
+                            output_hidden_states)
+
+    overlap_text_tower = True
+    _side = None
+
+    def _text_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def _finish(self, image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict, output_hidden_states):
         logits_per_text = logits_per_image = loss = None
         if return_loss or return_dict is False or output_hidden_states:
             # CLIP_ViP.py:1151-1158: tiny [B,B] fp32 product, only materialised on request (VidCLIP never asks)
