@@ -96,12 +96,13 @@ __device__ __forceinline__ void lstore_ks(char* tile, const u32x4 (&r)[4], int t
 // k-strided: rows % 128 == 0; operand bytes < 4 GiB.
 typedef __attribute__((address_space(3))) char lds_char;
 
-template <typename T, bool KS>
+template <typename T, bool KS, int NWV>
 struct GldsStager {
+  static constexpr int NPW = 16 / NWV;   // 1 KiB DMA pieces per wave per operand tile (16 KiB)
   __amdgpu_buffer_rsrc_t rsrc;
-  unsigned voff[4];     // per-lane byte offset of pass j at k-tile 0
+  unsigned voff[NPW];   // per-lane byte offset of this wave's piece j at k-tile 0
   unsigned step;        // byte advance per k-tile
-  unsigned lds_wave;    // wave-uniform byte offset of this wave's 1 KiB slot inside a 4 KiB pass
+  unsigned lds_wave;    // wave-uniform byte offset of this wave's first 1 KiB slot
 
   __device__ __forceinline__ void init(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t K, int64_t kbeg,
                                        int lane, int wave) {
@@ -110,18 +111,19 @@ struct GldsStager {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (unsigned)bytes, 0x00020000);
     lds_wave = wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPW; ++j) {
+      const int pass = j * NWV + wave;
       int64_t off;
       if constexpr (!KS) {
-        const int row = j * 32 + wave * 8 + (lane >> 3);
+        const int row = pass * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz128(row);
         off = ((row0 + row) * ld + kbeg) * ES + c * 16;
       } else if constexpr (sizeof(T) == 2) {
-        const int kr = j * 16 + wave * 4 + (lane >> 4), c16 = lane & 15;
+        const int kr = pass * 4 + (lane >> 4), c16 = lane & 15;
         const int src = (((c16 >> 1) ^ ks_f(kr)) << 1) | (c16 & 1);
         off = ((kbeg + kr) * ld + row0) * ES + src * 16;
       } else {
-        const int kr = j * 8 + wave * 2 + (lane >> 5), c32 = lane & 31;
+        const int kr = pass * 2 + (lane >> 5), c32 = lane & 31;
         const int col = (c32 * 4) ^ (((kr >> 2) & 1) << 4);
         off = ((kbeg + kr) * ld + row0 + col) * ES;
       }
@@ -136,10 +138,10 @@ struct GldsStager {
     lds_char* t3 = (lds_char*)tile;
     const unsigned adv = (unsigned)kt * step;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPW; ++j) {
       unsigned o = voff[j] + adv;
       if (o < voff[j]) o = 0xFFFFFFF0u;       // wrapped: was (and stays) out of bounds
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, t3 + (j * 4096 + lds_wave), 16, o, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, t3 + (j * NWV * 1024 + lds_wave), 16, o, 0, 0, 0);
     }
   }
 };
@@ -176,13 +178,17 @@ __device__ __forceinline__ typename Frag<T>::type lfrag(const char* tile, int ot
 
 // ---- the kernel -----------------------------------------------------------------------------------
 template <typename T, bool AKS, bool BKS, bool GLDS>
-__global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
+__global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto sA = [&](int s) -> char* { return smem + (2 * s) * TILE_BYTES; };
   auto sB = [&](int s) -> char* { return smem + (2 * s + 1) * TILE_BYTES; };
 
+  // register-staged family: 4 waves as 2x2, wave tile 64x64.  direct-to-LDS family: 8 waves as 2(M) x 4(N), wave tile
+  // 64x32 -- four waves per SIMD (two workgroups per CU) give the latency-bound stage loop twice the wave-level
+  // parallelism, and each wave issues only 4 DMA pieces per stage.
+  constexpr int NWV = GLDS ? 8 : 4, WN = GLDS ? 4 : 2, NTW = 8 / WN;     // NTW: 16-col sub-tiles per wave (2 / 4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // XCD-aware bijective remap: consecutive tile ids land on the same XCD (block b runs on XCD b % 8),
   // so tiles sharing an activation row-panel share one L2.
@@ -204,9 +210,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   const T* B = reinterpret_cast<const T*>(p.B);
   const Remap ident{0, 0, 0};
 
-  f32x4 acc[4][4];
+  f32x4 acc[NTW][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NTW; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
     if constexpr (BKS) lstore_ks<T>(sB(s), rb, tid); else lstore_kc<T>(sB(s), rb, tid);
   };
 
-  GldsStager<T, AKS> ga;
-  GldsStager<T, BKS> gb;
+  GldsStager<T, AKS, NWV> ga;
+  GldsStager<T, BKS, NWV> gb;
   if constexpr (GLDS) {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     ga.init(A, p.lda, m0, p.M, kend, kbeg, lane, wv);
@@ -252,13 +258,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
     XP_STAMP(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      typename Frag<T>::type fw[4], fx[4];
+      typename Frag<T>::type fw[NTW], fx[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fw[t] = lfrag<T, BKS>(sB(s), wn * 4 + t, ks, lane);
+      for (int t = 0; t < NTW; ++t) fw[t] = lfrag<T, BKS>(sB(s), wn * NTW + t, ks, lane);
 #pragma unroll
       for (int t = 0; t < 4; ++t) fx[t] = lfrag<T, AKS>(sA(s), wm * 4 + t, ks, lane);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
     }
@@ -286,8 +292,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
     for (int mt = 0; mt < 4; ++mt) {
       const int row = wm * 64 + mt * 16 + i16;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int chunk = wn * 16 + nt * 4 + g;
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int chunk = wn * (NTW * 4) + nt * 4 + g;
         *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[nt][mt];
       }
     }
@@ -298,13 +304,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
   if (p.wide) {          // 8 columns per lane: 16 lanes cover a row, 16 rows per pass, 16-byte bf16 stores
+    constexpr int RPP = NWV * 4;                    // rows per pass: 16 lanes per row
     const int c8 = tid & 15, r16 = tid >> 4;
     const int64_t n8 = n0 + c8 * 8;
     if (n8 < p.N) {
       const EpiLane8 el8(p, n8);
 #pragma unroll 4
-      for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 16 + r16;
+      for (int pass = 0; pass < 128 / RPP; ++pass) {
+        const int row = pass * RPP + r16;
         const int64_t m = m0 + row;
         if (m >= p.M) break;
         const char* rp = smem + row * 512;
@@ -322,8 +329,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
   const EpiLane el(p, n);
 
 #pragma unroll 4
-  for (int pass = 0; pass < 16; ++pass) {
-    const int row = pass * 8 + r8;
+  for (int pass = 0; pass < 128 / (NWV * 2); ++pass) {
+    const int row = pass * (NWV * 2) + r8;
     const int64_t m = m0 + row;
     if (m >= p.M) break;
     const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((c ^ (row & 7)) << 4));
@@ -335,10 +342,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(KParams p) {
 template <typename T, bool GLDS>
 void launch2(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
   const size_t lds = 4 * TILE_BYTES;
-  if (!d->a_kstrided && !d->b_kstrided)      gemm_kernel<T, false, false, GLDS><<<grid, NT, lds, st>>>(kp);
-  else if (!d->a_kstrided && d->b_kstrided)  gemm_kernel<T, false, true, GLDS><<<grid, NT, lds, st>>>(kp);
-  else if (d->a_kstrided && d->b_kstrided)   gemm_kernel<T, true, true, GLDS><<<grid, NT, lds, st>>>(kp);
-  else                                       gemm_kernel<T, true, false, GLDS><<<grid, NT, lds, st>>>(kp);
+  if (!d->a_kstrided && !d->b_kstrided)      gemm_kernel<T, false, false, GLDS><<<grid, GLDS ? 2 * NT : NT, lds, st>>>(kp);
+  else if (!d->a_kstrided && d->b_kstrided)  gemm_kernel<T, false, true, GLDS><<<grid, GLDS ? 2 * NT : NT, lds, st>>>(kp);
+  else if (d->a_kstrided && d->b_kstrided)   gemm_kernel<T, true, true, GLDS><<<grid, GLDS ? 2 * NT : NT, lds, st>>>(kp);
+  else                                       gemm_kernel<T, true, false, GLDS><<<grid, GLDS ? 2 * NT : NT, lds, st>>>(kp);
 }
 
 // The direct-to-LDS path needs dense, un-remapped operands whose tails the buffer bounds check can zero-fill.
