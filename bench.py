@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--txt-len", type=int, default=32)
+    ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step in a HIP graph and replay it "
+                    "(works; measured 23.3 vs 23.1 ms/step eager on MI355X -- the step is GPU-bound and replaying a "
+                    "600-node multi-stream graph costs the host as much as the eager launches); 0 (default): eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     return ap.parse_args()
@@ -125,8 +128,9 @@ def main():
     reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True)
     decay = [p for n, p in model.named_parameters() if p.dim() >= 2 and "logit_scale" not in n]
     no_decay = [p for n, p in model.named_parameters() if not (p.dim() >= 2 and "logit_scale" not in n)]
+    use_graph = a.graph == 1
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=5e-6, betas=(0.9, 0.98), eps=1e-6, fused=True)
+                            lr=5e-6, betas=(0.9, 0.98), eps=1e-6, fused=True, capturable=use_graph)
     video, ids, mask = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank)
     video, ids, mask = video.to(dev), ids.to(dev), mask.to(dev)
     logit_scale = model.clipmodel.logit_scale
@@ -150,9 +154,33 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        loss = step()
+    cap_stream = torch.cuda.Stream(device=dev) if use_graph else None
+    if use_graph:                      # warm up on the stream the graph will be captured on (AccumulateGrad nodes
+        cap_stream.wait_stream(torch.cuda.current_stream())      # bind to the stream of their first use)
+        with torch.cuda.stream(cap_stream):
+            for _ in range(a.warmup):
+                loss = step()
+        torch.cuda.current_stream().wait_stream(cap_stream)
+    else:
+        for _ in range(a.warmup):
+            loss = step()
     sync()
+    if use_graph:
+        # The step has no host-side data dependence (no .item(), static shapes, workspaces cached), so the ~600 kernel
+        # launches are captured once into a HIP graph and replayed: no Python / ctypes / launch cost per kernel.
+        eager_step = step
+        graph = torch.cuda.CUDAGraph()
+        static = {}
+        loss = None
+        with torch.cuda.graph(graph, stream=cap_stream):
+            static["loss"] = eager_step()
+
+        def step():                                                       # noqa: F811
+            graph.replay()
+            return static["loss"]
+        for _ in range(2):
+            loss = step()
+        sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
@@ -191,7 +219,8 @@ def main():
             "config": {"workload": f"CLIP-ViP ViT-B/{a.patch} video-text contrastive train step (fwd+loss+bwd+grad-sync+"
                                    f"clip+AdamW), {a.frames} frames {a.res}^2, {a.txt_len} text tokens, "
                                    f"local batch {a.batch}, BASELINE configs[1]" + ("" if W == 1 else "/[2]"),
-                       "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4)},
+                       "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4),
+                       "launch": "hipGraph replay of the captured step" if use_graph else "eager"},
             "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
             "step_frac_of_bf16_peak": round(step_flops / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),

@@ -167,6 +167,8 @@ int xp_nce_loss(const float* vis, const float* txt, const float* log_scale, floa
  * this library relies on (out buffers are small device arrays; see csrc/probe.hip). */
 /* cycle-stamp trace of the 128x128 GEMM main loop (tools/gemm_trace.py); pass NULL to disable.  buffer: >= 1 KiB */
 int xp_debug_set_gemm_trace(void* device_buffer);
+/* resident workgroups per CU of the default bf16 GEMM kernel at `lds_bytes` of dynamic LDS (occupancy API) */
+int xp_debug_gemm_occupancy(int lds_bytes);
 int xp_probe_mfma_bf16(const void* a, const void* b, float* c, void* stream);
 int xp_probe_mfma_f32(const float* a, const float* b, float* c, void* stream);
 int xp_probe_tr16(const void* in /*4096 u16*/, const int32_t* lane_byte_off /*64*/, void* out /*64*4 u16*/, void* stream);

@@ -439,6 +439,14 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
 
 }  // namespace
 
+// occupancy query for the default bf16 NT direct-to-LDS kernel: resident workgroups per CU at `lds_bytes` dynamic LDS
+extern "C" int xp_debug_gemm_occupancy(int lds_bytes) {
+  int nb = -1;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<bf16_t, false, false, true>, 2 * NT, (size_t)lds_bytes);
+  if (e != hipSuccess) return -(int)e;
+  return nb;
+}
+
 static unsigned long long* g_gemm_trace = nullptr;
 extern "C" int xp_debug_set_gemm_trace(void* device_buffer) { g_gemm_trace = (unsigned long long*)device_buffer; return XP_OK; }
 
