@@ -198,7 +198,8 @@ __global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+  int tm, tn;
+  tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   constexpr int KE = BKB / sizeof(T);
@@ -489,6 +490,11 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.dbg = g_gemm_trace;
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
+  {
+    static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 8;
+    const int ngroups = (int)cdiv(kp.tiles_n, gmax);
+    kp.group_n = (int)cdiv(kp.tiles_n, ngroups);
+  }
   const int zsplits = (int)cdiv(d->K, kp.k_per_split);
   XP_REQUIRE(split == 1 || zsplits == split, "xp_gemm: split_k=%d leaves empty slabs for K=%lld (use <= %d)",
              split, (long long)d->K, zsplits);

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = xcd_remap(blockIdx.x, nwg);
-  const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+  int tm, tn;
+  tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
   const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
 
   constexpr int KE = SKB / sizeof(T);
@@ -281,6 +282,7 @@ bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStre
   kp.k_per_split = cdiv(cdiv(d->K, split), ke) * ke;
   if (split > 1 && cdiv(d->K, kp.k_per_split) != split) return false;
   kp.tiles_m = (int)cdiv(d->M, TM); kp.tiles_n = (int)cdiv(d->N, TN);
+  kp.group_n = kp.tiles_n;
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   if (d->in_dtype == XP_BF16) launch_t<bf16_t>(d, kp, grid, st);
   else                        launch_t<float>(d, kp, grid, st);
