@@ -491,7 +491,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
   {
-    static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 8;
+    static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 4;
     const int ngroups = (int)cdiv(kp.tiles_n, gmax);
     kp.group_n = (int)cdiv(kp.tiles_n, ngroups);
   }
