@@ -193,11 +193,7 @@ __global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
   // XCD-aware bijective remap: consecutive tile ids land on the same XCD (block b runs on XCD b % 8),
   // so tiles sharing an activation row-panel share one L2.
   const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int bid = xcd_remap(blockIdx.x, nwg, p.xcd_remap);
   int tm, tn;
   tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
@@ -494,6 +490,8 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
     static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 4;
     const int ngroups = (int)cdiv(kp.tiles_n, gmax);
     kp.group_n = (int)cdiv(kp.tiles_n, ngroups);
+    static const int xr = getenv("XPRETRAIN_GEMM_NO_XCD") ? 0 : 1;
+    kp.xcd_remap = xr;
   }
   const int zsplits = (int)cdiv(d->K, kp.k_per_split);
   XP_REQUIRE(split == 1 || zsplits == split, "xp_gemm: split_k=%d leaves empty slabs for K=%lld (use <= %d)",

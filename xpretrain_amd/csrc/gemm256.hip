@@ -282,7 +282,7 @@ bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStre
   kp.k_per_split = cdiv(cdiv(d->K, split), ke) * ke;
   if (split > 1 && cdiv(d->K, kp.k_per_split) != split) return false;
   kp.tiles_m = (int)cdiv(d->M, TM); kp.tiles_n = (int)cdiv(d->N, TN);
-  kp.group_n = kp.tiles_n;
+  kp.group_n = kp.tiles_n; kp.xcd_remap = 1;
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   if (d->in_dtype == XP_BF16) launch_t<bf16_t>(d, kp, grid, st);
   else                        launch_t<float>(d, kp, grid, st);

@@ -23,6 +23,7 @@ struct KParams {
   const float* tab1; const float* tab2; int64_t tab_L;
   int tiles_m, tiles_n;
   int group_n;               // tile columns per L2 super-tile group (see tile_of)
+  int xcd_remap;             // 1: consecutive tile ids -> same XCD (default); 0: hardware round-robin (A/B switch)
   int wide;                  // 1: N, ldc, ldr, ldaux all multiples of 8 -> 8 columns per lane, 16-byte bf16 stores
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
@@ -103,7 +104,8 @@ __device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) <<
 
 // XCD-aware bijective remap of the linear workgroup id (block b runs on XCD b % 8): consecutive tile ids -- which
 // share an activation row panel -- land on one XCD / one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+__device__ __forceinline__ int xcd_remap(int bid, int nwg, int on = 1) {
+  if (!on) return bid;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
