@@ -28,7 +28,9 @@
 namespace {
 
 constexpr int DH = 64;
-constexpr int TQ = 64;            // rows per workgroup tile
+constexpr int TQ = 256;           // own-dimension rows per workgroup: 16 waves x 16 rows
+constexpr int NTHR = 1024;
+constexpr int GR = 256;           // other-dimension rows staged in LDS per load phase (4 tiles of 64)
 constexpr int TILE = 64 * 128;    // bytes of one [64][64] bf16 tile
 constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(float32).min, _expand_mask (:50-61)
 
@@ -87,6 +89,28 @@ __device__ __forceinline__ void load_tile_o(char* tile, const bf16_t* src, const
     *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = v;
   }
 }
+// ---- cooperative GROUP load: up to GR = 256 problem rows x 64 bf16 -> LDS as 4 swizzled [64][128 B] tiles.  A whole
+// ViT-B/16 frame problem (R = 200 rows) is fetched in ONE latency-bound phase by the 1024 threads (2 x 16 B each per
+// operand) and shared by all 16 waves: no per-tile global round trips, no per-tile barriers.  Rows >= R are zero-filled;
+// only the `ntiles` tiles that will be read are touched.
+__device__ __forceinline__ void load_group(char* base, const bf16_t* src, int64_t ld, int64_t col0, const AP& p,
+                                           const Prob& pr, int row0, int ntiles, int tid) {
+  const int c = tid & 7, rr = tid >> 3;
+  const int nrows = ntiles * 64;
+#pragma unroll
+  for (int j = 0; j < GR / 128; ++j) {
+    const int row = rr + 128 * j, r = row0 + row;
+    if (row < nrows) {
+      u32x4 v = {0, 0, 0, 0};
+      if (r < p.R) {
+        const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
+        v = *reinterpret_cast<const u32x4*>(src + t * ld + col0 + c * 8);
+      }
+      *reinterpret_cast<u32x4*>(base + (row >> 6) * TILE + tile128_off(row & 63, c)) = v;
+    }
+  }
+}
+
 // ---- split tile load (software pipelining): global -> registers is issued one tile AHEAD, under the MFMA work of the
 // current tile; registers -> LDS happens after the barrier that frees the tile.  One exposed global round trip per
 // workgroup instead of one per 64-row tile.
@@ -142,9 +166,9 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 constexpr int PART = 2 + DH;   // forward proxy partial: m, l, O[64]
 
 // ============================================================================================ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
-  char* sK = smem; char* sV = smem + TILE; unsigned char* sPad = reinterpret_cast<unsigned char*>(smem + 2 * TILE);
+__global__ __launch_bounds__(NTHR) void attn_fwd_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + GR];
+  char* gK = smem; char* gV = smem + 4 * TILE; unsigned char* gPad = reinterpret_cast<unsigned char*>(smem + 8 * TILE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
   const Prob pr(p, blockIdx.y);
   const int qb = blockIdx.x * TQ;
@@ -163,23 +187,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AP p) {
   int ntiles = (p.R + 63) / 64;
   if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
 
-  u32x4 rK[2], rV[2];
-  unsigned char rPad = 0;
   const int64_t kcol = (int64_t)p.H * DH + pr.h * DH, vcol = (int64_t)2 * p.H * DH + pr.h * DH;
-  auto prefetch = [&](int kt) {
-    gload_tile(rK, p.qkv, p.ldqkv, kcol, p, pr, kt * 64, tid);
-    gload_tile(rV, p.qkv, p.ldqkv, vcol, p, pr, kt * 64, tid);
-    const int r = kt * 64 + (tid & 63);
-    rPad = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
-  };
-  if (ntiles > 0) prefetch(0);
+  const bool wave_active = qb + wave * 16 < p.R;        // wave-uniform: waves past the last row only keep the barriers
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * 64;
-    lstore_tile(sK, rK, tid);
-    lstore_tile(sV, rV, tid);
-    if (tid < 64) sPad[tid] = rPad;
-    __syncthreads();
-    if (kt + 1 < ntiles) prefetch(kt + 1);
+    if ((kt & 3) == 0) {                                // new key group: ONE load phase for up to 4 tiles
+      if (kt) __syncthreads();
+      const int nt = ntiles - kt < 4 ? ntiles - kt : 4;
+      load_group(gK, p.qkv, p.ldqkv, kcol, p, pr, kb, nt, tid);
+      load_group(gV, p.qkv, p.ldqkv, vcol, p, pr, kb, nt, tid);
+      if (tid < GR) { const int r = kb + tid; gPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0; }
+      __syncthreads();
+    }
+    if (!wave_active) continue;
+    const char* sK = gK + (kt & 3) * TILE;
+    const char* sV = gV + (kt & 3) * TILE;
+    const unsigned char* sPad = gPad + (kt & 3) * 64;
 
     f32x4 s[4];
 #pragma unroll
@@ -189,17 +212,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AP p) {
       for (int kk = 0; kk < 2; ++kk) s[t] = mma16(frag_rows(sK, t, kk, lane), qf[kk], s[t]);
     }
     float tmax = -INFINITY;
+    // masking is only needed (wave-uniformly) on the tail tile, with a padding mask, on the causal diagonal band, or
+    // where proxy rows meet proxy keys in a frame n != 0 -- every other (wave, tile) pair takes the mask-free path
+    // (the mask logic was ~half of this kernel's VALU work).  Lanes of invalid query rows compute discarded values.
+    const int wrow0 = qb + wave * 16;
+    const bool need_mask = kb + 64 > p.R || p.pad != nullptr ||
+        (p.mode == XP_ATTN_CAUSAL ? kb + 63 > wrow0 : (pr.n != 0 && kb < p.M && wrow0 < p.M));
+    if (need_mask) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kl = t * 16 + 4 * g + r, rk = kb + kl;
-        float v = s[t][r];
-        if (sPad[kl]) v = F32_MIN;
-        if (!(qvalid && rk < p.R && allowed(p, pr.n, rq, rk))) v = -INFINITY;
-        s[t][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int kl = t * 16 + 4 * g + r, rk = kb + kl;
+          float v = s[t][r];
+          if (sPad[kl]) v = F32_MIN;
+          if (!(qvalid && rk < p.R && allowed(p, pr.n, rq, rk))) v = -INFINITY;
+          s[t][r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[t][r]);
+    }
     tmax = group_max(tmax);
     const float mnew = fmaxf(m, tmax);
     const float msafe = mnew == -INFINITY ? 0.f : mnew;
@@ -219,7 +255,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AP p) {
       o[dt] = mma16(frag_cols(sV, dt, 0, lane), pf0, o[dt]);
       o[dt] = mma16(frag_cols(sV, dt, 1, lane), pf1, o[dt]);
     }
-    __syncthreads();
   }
   l = group_sum(l);
   if (!qvalid) return;
@@ -279,10 +314,10 @@ __global__ void attn_delta_kernel(AP p) {
 }
 
 // dK, dV: workgroup = 64 key rows of one problem; loops over the problem's query tiles.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 3 * 64 * 4];
-  char* sQ = smem; char* sDO = smem + TILE;
-  float* sM = reinterpret_cast<float*>(smem + 2 * TILE); float* sLg = sM + 64; float* sDl = sLg + 64;
+__global__ __launch_bounds__(NTHR) void attn_bwd_dkv_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + 3 * GR * 4];
+  char* gQ = smem; char* gDO = smem + 4 * TILE;
+  float* gM = reinterpret_cast<float*>(smem + 8 * TILE); float* gLg = gM + GR; float* gDl = gLg + GR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
   const Prob pr(p, blockIdx.y);
   const int kb = blockIdx.x * TQ;
@@ -301,28 +336,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
 
   const int ntiles = (p.R + 63) / 64;
   const int qt0 = p.mode == XP_ATTN_CAUSAL ? kb / 64 : 0;     // queries before the first key never see it
-  u32x4 rQ[2], rDO[2];
-  float rM = 0.f, rLg = 0.f, rDl = 0.f;
-  auto prefetch = [&](int qt) {
-    gload_tile(rQ, p.qkv, p.ldqkv, (int64_t)pr.h * DH, p, pr, qt * 64, tid);
-    gload_tile(rDO, p.dout, p.ldo, (int64_t)pr.h * DH, p, pr, qt * 64, tid);
-    const int r = qt * 64 + (tid & 63);
-    rM = 0.f; rLg = 0.f; rDl = 0.f;
-    if (tid < 64 && r < p.R) {
-      const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
-      rM = p.stats[si * 2]; rLg = p.stats[si * 2 + 1]; rDl = p.ws0[si];
-    }
-  };
-  if (qt0 < ntiles) prefetch(qt0);
+  const bool wave_active = kb + wave * 16 < p.R;
   for (int qt = qt0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
-    lstore_tile(sQ, rQ, tid);
-    lstore_tile(sDO, rDO, tid);
-    if (tid < 64) { sM[tid] = rM; sLg[tid] = rLg; sDl[tid] = rDl; }
-    __syncthreads();
-    if (qt + 1 < ntiles) prefetch(qt + 1);
+    const int gi = (qt - qt0) & 3;
+    if (gi == 0) {                                      // new query group: ONE load phase for up to 4 tiles
+      if (qt != qt0) __syncthreads();
+      const int nt = ntiles - qt < 4 ? ntiles - qt : 4;
+      load_group(gQ, p.qkv, p.ldqkv, (int64_t)pr.h * DH, p, pr, qb, nt, tid);
+      load_group(gDO, p.dout, p.ldo, (int64_t)pr.h * DH, p, pr, qb, nt, tid);
+      if (tid < GR) {
+        const int r = qb + tid;
+        float mm = 0.f, lg = 0.f, dl = 0.f;
+        if (r < p.R) {
+          const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
+          mm = p.stats[si * 2]; lg = p.stats[si * 2 + 1]; dl = p.ws0[si];
+        }
+        gM[tid] = mm; gLg[tid] = lg; gDl[tid] = dl;
+      }
+      __syncthreads();
+    }
+    if (!wave_active) continue;
+    const char* sQ = gQ + gi * TILE;
+    const char* sDO = gDO + gi * TILE;
+    const float* sM = gM + gi * 64; const float* sLg = gLg + gi * 64; const float* sDl = gDl + gi * 64;
 
     f32x4 pp[4], ds[4];
+    // mask-free path unless a padding mask exists, the causal band crosses this (query tile, key wave) pair, or proxy
+    // queries meet proxy keys in a frame n != 0.  Query rows >= R have zero-filled Q/dO rows and (m, log l) = 0, so
+    // their P is finite and multiplies zeros; key lanes >= R only produce their own (discarded) columns.
+    const int wkey0 = kb + wave * 16;
+    const bool need_mask = p.pad != nullptr ||
+        (p.mode == XP_ATTN_CAUSAL ? qb < wkey0 + 15 : (pr.n != 0 && wkey0 < p.M && qb < p.M));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
@@ -331,16 +376,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
         s = mma16(frag_rows(sQ, t, kk, lane), kf[kk], s);
         dp = mma16(frag_rows(sDO, t, kk, lane), vf[kk], dp);
       }
+      // the lane's 4 query rows are consecutive: one 16-byte LDS read per statistic instead of four 4-byte reads
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(sM + t * 16 + 4 * g);
+      const f32x4 lg4 = *reinterpret_cast<const f32x4*>(sLg + t * 16 + 4 * g);
+      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sDl + t * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ql = t * 16 + 4 * g + r, rqq = qb + ql;
-        float pv = 0.f;
-        if (kvalid && rqq < p.R && allowed(p, pr.n, rqq, rk)) {
-          const float sv = kpad ? F32_MIN : s[r];
-          pv = __expf((sv - sM[ql]) - sLg[ql]);
+        const int rqq = qb + t * 16 + 4 * g + r;
+        float pv;
+        if (need_mask) {
+          pv = 0.f;
+          if (kvalid && rqq < p.R && allowed(p, pr.n, rqq, rk)) {
+            const float sv = kpad ? F32_MIN : s[r];
+            pv = __expf((sv - m4[r]) - lg4[r]);
+          }
+        } else {
+          pv = __expf((s[r] - m4[r]) - lg4[r]);
         }
         pp[t][r] = pv;
-        ds[t][r] = pv * (dp[r] - sDl[ql]);
+        ds[t][r] = pv * (dp[r] - dl4[r]);
       }
     }
     const bf16x8 pf0 = pack_p(pp[0], pp[1]), pf1 = pack_p(pp[2], pp[3]);
@@ -352,7 +406,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
       dk[dt] = mma16(frag_cols(sQ, dt, 0, lane), sf0, dk[dt]);
       dk[dt] = mma16(frag_cols(sQ, dt, 1, lane), sf1, dk[dt]);
     }
-    __syncthreads();
   }
   if (!kvalid) return;
   if (p.mode == XP_ATTN_PROXY && rk < p.M) {
@@ -370,9 +423,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AP p) {
 }
 
 // dQ: workgroup = 64 query rows; loops over key tiles (transposed orientation, per-lane query scalars).
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
-  char* sK = smem; char* sV = smem + TILE; unsigned char* sPad = reinterpret_cast<unsigned char*>(smem + 2 * TILE);
+__global__ __launch_bounds__(NTHR) void attn_bwd_dq_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + GR];
+  char* gK = smem; char* gV = smem + 4 * TILE; unsigned char* gPad = reinterpret_cast<unsigned char*>(smem + 8 * TILE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
   const Prob pr(p, blockIdx.y);
   const int qb = blockIdx.x * TQ;
@@ -394,24 +447,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AP p) {
 
   int ntiles = (p.R + 63) / 64;
   if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
-  u32x4 rK[2], rV[2];
-  unsigned char rPad = 0;
   const int64_t kcol = (int64_t)p.H * DH + pr.h * DH, vcol = (int64_t)2 * p.H * DH + pr.h * DH;
-  auto prefetch = [&](int kt) {
-    gload_tile(rK, p.qkv, p.ldqkv, kcol, p, pr, kt * 64, tid);
-    gload_tile(rV, p.qkv, p.ldqkv, vcol, p, pr, kt * 64, tid);
-    const int r = kt * 64 + (tid & 63);
-    rPad = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0;
-  };
-  if (ntiles > 0) prefetch(0);
+  const bool wave_active = qb + wave * 16 < p.R;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * 64;
-    lstore_tile(sK, rK, tid);
-    lstore_tile(sV, rV, tid);
-    if (tid < 64) sPad[tid] = rPad;
-    __syncthreads();
-    if (kt + 1 < ntiles) prefetch(kt + 1);
+    if ((kt & 3) == 0) {
+      if (kt) __syncthreads();
+      const int nt = ntiles - kt < 4 ? ntiles - kt : 4;
+      load_group(gK, p.qkv, p.ldqkv, kcol, p, pr, kb, nt, tid);
+      load_group(gV, p.qkv, p.ldqkv, vcol, p, pr, kb, nt, tid);
+      if (tid < GR) { const int r = kb + tid; gPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0; }
+      __syncthreads();
+    }
+    if (!wave_active) continue;
+    const char* sK = gK + (kt & 3) * TILE;
+    const char* sV = gV + (kt & 3) * TILE;
+    const unsigned char* sPad = gPad + (kt & 3) * 64;
     f32x4 ds[4];
+    const int wrow0 = qb + wave * 16;
+    const bool need_mask = kb + 64 > p.R || p.pad != nullptr ||
+        (p.mode == XP_ATTN_CAUSAL ? kb + 63 > wrow0 : (pr.n != 0 && kb < p.M && wrow0 < p.M));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
@@ -423,10 +478,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kl = t * 16 + 4 * g + r, rk = kb + kl;
-        float pv = 0.f;
-        if (qvalid && rk < p.R && allowed(p, pr.n, rq, rk)) {
-          const float sv = sPad[kl] ? F32_MIN : s[r];
-          pv = __expf((sv - mq) - lgq);
+        float pv;
+        if (need_mask) {
+          pv = 0.f;
+          if (qvalid && rk < p.R && allowed(p, pr.n, rq, rk)) {
+            const float sv = sPad[kl] ? F32_MIN : s[r];
+            pv = __expf((sv - mq) - lgq);
+          }
+        } else {
+          pv = __expf((s[r] - mq) - lgq);
         }
         ds[t][r] = pv * (dp[r] - dlq);
       }
@@ -437,7 +497,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AP p) {
       dq[dt] = mma16(frag_cols(sK, dt, 0, lane), sf0, dq[dt]);
       dq[dt] = mma16(frag_cols(sK, dt, 1, lane), sf1, dq[dt]);
     }
-    __syncthreads();
   }
   if (!qvalid) return;
   if (p.mode == XP_ATTN_PROXY && rq < p.M) {
@@ -509,7 +568,7 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   p.ws0 = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv(p.R, TQ), (unsigned)(B * H * N));
-  attn_fwd_kernel<<<grid, 256, 0, st>>>(p);
+  attn_fwd_kernel<<<grid, NTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_fwd");
   if (mode == XP_ATTN_PROXY) {
     attn_fwd_merge_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
@@ -538,9 +597,9 @@ extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, cons
   attn_delta_kernel<<<(unsigned)cdiv(B * S * H, 256), 256, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(delta)");
   dim3 grid((unsigned)cdiv(p.R, TQ), (unsigned)P);
-  attn_bwd_dkv_kernel<<<grid, 256, 0, st>>>(p);
+  attn_bwd_dkv_kernel<<<grid, NTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
-  attn_bwd_dq_kernel<<<grid, 256, 0, st>>>(p);
+  attn_bwd_dq_kernel<<<grid, NTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
   if (mode == XP_ATTN_PROXY) {
     attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
