@@ -121,3 +121,24 @@ def test_second_pass_T1_interpolated_temporal_embedding():
     g = model.clipmodel.vision_model.embeddings.temporal_embedding.grad.cpu()
     gr = sd["vision_model.embeddings.temporal_embedding"].grad
     assert report("temporal_embedding grad (T=1 interp)", g, gr, 6e-2) <= 6e-2
+
+
+def test_weight_cache_follows_optimizer_steps():
+    """bf16 weight copies must track the fp32 masters across (fused) optimizer steps: two SGD-like steps change the
+    features; a stale cache would reproduce the first output exactly."""
+    from xpretrain_amd.modeling import VidCLIP
+    torch.manual_seed(3)
+    cfgd = O.hf_config_dict(128, 2, 1, 256, 16, 32, 128, 2, 1, 256, 120, 16, 64)
+    model = VidCLIP(_Args(cfgd, 2)).cuda()
+    video, ids, mask = O.synthetic_inputs(2, 2, 32, 8, vocab=120)
+    video, ids, mask = video.cuda(), ids.cuda(), mask.cuda()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=True)
+    f0 = model(video, ids, mask)["vis_features"].detach().clone()
+    model(video, ids, mask)["vis_features"].sum().backward()
+    opt.step()
+    f1 = model(video, ids, mask)["vis_features"].detach()
+    assert (f1 - f0).abs().max().item() > 1e-3
+    # and the refreshed copy equals the master weights: compare against the oracle on the updated state dict
+    sd = {k: v.detach().cpu() for k, v in O.strip_prefix(model.state_dict()).items()}
+    ref, _ = O.clip_features(video.cpu(), ids.cpu(), mask.cpu(), sd, O.OracleCfg.from_hf_dict(cfgd, temporal_size=2))
+    assert (f1.cpu() - ref).abs().max().item() < 2e-2

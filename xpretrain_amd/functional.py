@@ -24,11 +24,24 @@ from . import hip_ops as H
 
 # ------------------------------------------------------------------------------------------ weights
 class WeightCache:
-    """Compute-dtype copies of fp32 master weights, refreshed when the parameter's version counter moves
-    (optimizer steps / load_state_dict bump ``Tensor._version``)."""
+    """Compute-dtype copies of fp32 master weights.  An entry is refreshed when (a) the parameter's version counter
+    moved (``load_state_dict`` / in-place edits), or (b) ANY optimizer stepped since the copy was made -- fused / foreach
+    optimizers update parameters without bumping ``Tensor._version`` (observed with ``AdamW(fused=True)``), so a global
+    optimizer-step hook advances ``generation``.  ``invalidate()`` forces a refresh by hand."""
 
     def __init__(self):
         self._c = {}
+        self.generation = 0
+        self._hooked = False
+
+    def _ensure_hook(self):
+        if not self._hooked:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            register_optimizer_step_post_hook(lambda opt, args, kwargs: self.invalidate())
+            self._hooked = True
+
+    def invalidate(self):
+        self.generation += 1
 
     @staticmethod
     def _alive(ent, ws) -> bool:
@@ -39,9 +52,10 @@ class WeightCache:
     def get(self, w: torch.Tensor, dtype) -> torch.Tensor:
         if dtype == torch.float32:
             return w.detach()
+        self._ensure_hook()
         key = (id(w), dtype)
         ent = self._c.get(key)
-        ver = (w._version, w.data_ptr())
+        ver = (w._version, w.data_ptr(), self.generation)
         if not self._alive(ent, (w,)) or ent[0] != ver:
             buf = ent[1] if ent is not None and ent[1].shape == w.shape and ent[1].device == w.device else None
             ent = (ver, H.cast(w.detach(), dtype, out=buf), (weakref.ref(w),))
@@ -50,8 +64,9 @@ class WeightCache:
 
     def fused(self, ws, dtype) -> torch.Tensor:
         """Row-concatenation of several [n_i, k] weights (or 1-D biases) in `dtype`: the fused QKV operand."""
+        self._ensure_hook()
         key = (tuple(id(w) for w in ws), dtype)
-        ver = tuple((w._version, w.data_ptr()) for w in ws)
+        ver = tuple((w._version, w.data_ptr(), self.generation) for w in ws)
         ent = self._c.get(key)
         if not self._alive(ent, ws) or ent[0] != ver:
             rows = sum(w.shape[0] for w in ws)
