@@ -74,6 +74,12 @@ typedef struct XpGemmDesc {
 
 int xp_gemm(const XpGemmDesc* desc, void* stream);
 
+/* Split-K factor xp_gemm should be given for a weight-gradient-shaped problem (dW = dY^T X as computed by the
+ * backward of nn.Linear inside CLIPEncoderLayer, modeling/CLIP_ViP.py:383-396,444-460): fills one resident round
+ * of workgroups of the kernel family xp_gemm will pick for `desc` (desc->split_k and the data pointers are
+ * ignored).  The value is always accepted by xp_gemm (whole k-steps per slab, no empty slab); 1 = no split. */
+int32_t xp_gemm_auto_split(const XpGemmDesc* desc);
+
 /* out[i] (+)= sum_z slabs[z*n + i], fp32; accumulate != 0 adds into out (gradient accumulation). */
 int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
 

@@ -129,7 +129,8 @@ def test_bad_arguments_raise():
 # ---------------------------------------------------------------------------------------------- 256x256 family
 @pytest.fixture
 def force_gemm256(monkeypatch):
-    monkeypatch.setenv("XPRETRAIN_GEMM256", "2")     # use the deep-pipelined family whenever its preconditions hold
+    monkeypatch.setenv("XPRETRAIN_GEMM256", "2")     # use the 256x256 family whenever its preconditions hold
+    monkeypatch.setenv("XPRETRAIN_GEMM256_SPLITK", "1")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

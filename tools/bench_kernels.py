@@ -48,7 +48,7 @@ def bench_gemm():
         print(f"gemm dX  {name:4s}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
         # dW[N,K] = dY^T X, split-K
         import os
-        for split in ((7, 9, 14, 28) if os.environ.get('XPRETRAIN_GEMM256_SPLITK') else tuple(int(x) for x in os.environ.get('SPLITS', '4,8,16').split(','))):
+        for split in tuple(int(x) for x in os.environ.get('SPLITS', '4,8,16').split(',')):
             slabs = torch.empty(split, N, K, device="cuda")
             dW = torch.empty(N, K, device="cuda")
             def f():

@@ -46,6 +46,7 @@ SIGNATURES = {
     "xp_abi_version": (i32, []),
     "xp_last_error": (C.c_char_p, []),
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
+    "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
     "xp_splitk_reduce": (i32, [vp, vp, i64, i32, i32, vp]),
     "xp_colsum_workspace_bytes": (sz, [i64, i64]),
     "xp_colsum": (i32, [vp, i64, i64, i64, i32, vp, i32, vp, sz, vp]),

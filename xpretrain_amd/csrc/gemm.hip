@@ -300,6 +300,31 @@ __global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
+  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c) {
+    constexpr int EPI = decltype(epi_c)::value;
+    constexpr bool F32 = decltype(f32_c)::value;
+    constexpr int RPP = NWV * 4, NP = 128 / RPP;    // 16 lanes per row, RPP rows per pass
+    const int c8 = tid & 15, r16 = tid >> 4;
+    const FastEpi<T, EPI, F32> fe(p, F32 ? (void*)Cf : (void*)Ct, n0 + c8 * 8);
+    const unsigned mrow = (unsigned)m0 + r16;
+    Raw8<T> pre[NP];
+    if constexpr (EpiTraits<EPI>::pre) {
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) pre[pass] = fe.load_pre(mrow + pass * RPP);
+    }
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+      const int row = pass * RPP + r16;
+      const char* rp = smem + row * 512;
+      const f32x8 v = {*reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ (row & 7)) << 4)),
+                       *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ (row & 7)) << 4))};
+      fe.finish(v, pre[pass], mrow + pass * RPP);
+    }
+  });
+  if (fast) {
+    if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
+    return;
+  }
   if (p.wide) {          // 8 columns per lane: 16 lanes cover a row, 16 rows per pass, 16-byte bf16 stores
     constexpr int RPP = NWV * 4;                    // rows per pass: 16 lanes per row
     const int c8 = tid & 15, r16 = tid >> 4;
@@ -485,6 +510,13 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
   kp.dbg = g_gemm_trace;
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
+  {
+    // fast epilogue (gemm_common.h): 32-bit buffer offsets must not wrap for any row of the last tile
+    const int64_t osz = kp.out_f32 ? 4 : esz, lim = (int64_t)EPI_OOB - 64;
+    const int64_t rows = d->M + 256;
+    kp.fast_epi = (kp.wide && d->c_grp == 0 && !getenv("XPRETRAIN_GEMM_SLOW_EPI") && rows * d->ldc * osz < lim &&
+                   (!d->resid || rows * d->ldr * esz < lim) && (!d->aux || rows * d->ldaux * osz < lim)) ? 1 : 0;
+  }
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
   {
     static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 4;
@@ -498,7 +530,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
              split, (long long)d->K, zsplits);
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   hipStream_t st = (hipStream_t)stream;
-  if ((split == 1 || getenv("XPRETRAIN_GEMM256_SPLITK")) && xp_gemm256_try(d, kp, st)) {     // large dense problems: 256x256 deep-pipelined family
+  if (xp_gemm256_try(d, kp, st)) {     // large dense problems: 256x256 ping-pong family
     XP_CHECK_LAUNCH("xp_gemm(256)");
     return XP_OK;
   }
@@ -506,6 +538,27 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   else                        launch<float>(d, kp, grid, st);
   XP_CHECK_LAUNCH("xp_gemm");
   return XP_OK;
+}
+
+// split s0 rounded to one xp_gemm accepts (whole k-steps per slab, no empty slab)
+static int valid_split(int64_t K, int64_t s0, int64_t ke) {
+  if (s0 <= 1) return 1;
+  const int64_t kps = cdiv(cdiv(K, s0), ke) * ke;
+  return (int)cdiv(K, kps);
+}
+
+extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 1;
+  const int esz = d->in_dtype == XP_BF16 ? 2 : 4;
+  const int64_t ke = BKB / esz;
+  const int64_t t256 = cdiv(d->M, 256) * cdiv(d->N, 256);
+  int64_t s0 = 256 / t256 < d->K / 512 ? 256 / t256 : d->K / 512;
+  const int s256 = valid_split(d->K, s0, 64);
+  if (xp_gemm256_wanted(d, s256)) return s256;
+  const int64_t t128 = cdiv(d->M, BM) * cdiv(d->N, BN);
+  if (t128 >= 256) return 1;
+  s0 = 512 / t128 < d->K / 512 ? 512 / t128 : d->K / 512;
+  return valid_split(d->K, s0, ke);
 }
 
 extern "C" int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32_t splits, int32_t accumulate,

@@ -1,30 +1,32 @@
-// 256x256-tile MFMA GEMM (experimental second family; OFF by default, XPRETRAIN_GEMM256=1|2 enables it).
+// 256x256-tile MFMA GEMM, 8-wave ping-pong main loop (second kernel family; XPRETRAIN_GEMM256=0|1|2, see xp_gemm256_wanted).
 //
-// Motivation (measured on MI355X with tools/gemm_trace.py, s_memtime stamps inside the 128x128 kernel): one k-iteration
-// of the production kernel costs 2200-3000 cycles per wave for 544 cycles of MFMA work -- ~700-1100 cycles ISSUING its
-// eight 1-KiB buffer_load...lds pieces (the CU's texture-address path moves 64 B/clk, and a 128x128x64 stage needs 32 KiB
-// per 544 MFMA-cycles, i.e. the TA is ~94 % as busy as the matrix pipe), ~320-600 cycles waiting for the DMA and ~330 at
-// the barrier.  A 256x256 tile halves the bytes that cross the TA per FLOP.
+// Why a second family (measured on MI355X with tools/gemm_trace.py, s_memtime stamps inside the 128x128 kernel): a
+// 128x128x64 stage moves 32 KiB through the CU's texture-address path (64 B/clk) per 512 cycles of MFMA work per SIMD,
+// i.e. the LDS-DMA path is as busy as the matrix pipe and one k-iteration costs 2200-3000 cycles.  A 256x256 tile halves
+// the bytes staged per FLOP (64 KiB per 2048 MFMA cycles) and doubles the MFMAs per LDS fragment read.
 //
-//   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 accumulators (128 VGPRs)
-//   stage      128 BYTES of k (64 bf16 / 32 f32), 256 + 256 rows = 64 KiB; 2 stages = 128 KiB LDS, 1 workgroup / CU
-//              (64-byte-row stages measured 0.7x: half-line L1 fills double the L2->L1 traffic)
-//   per stage  s_waitcnt vmcnt(0) ; raw s_barrier ; issue stage t+1 ; 2 x (12 fragment reads + 32 MFMA) per wave
-//   epilogue   wave-private LDS staging (rounds of 32 rows x 64 cols fp32), row-major read-back, shared fused epilogue
+//   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 accumulators (128 registers)
+//   k-tile     64 bf16 of k = four 16 KiB HALF-TILES, consumed in the order A0, B0, B1, A1.  Half h of the M-side tile
+//              holds rows {wm*128 + h*64 + r} (r < 64) of both wave rows, half h of the N-side tile rows
+//              {wn*64 + h*32 + r} (r < 32) of all four wave columns: every wave needs 64 x 32 of its output per
+//              (A half, B half) pair, so one k-tile is four PHASES of 16 MFMAs: (A0,B0) (A0,B1) (A1,B1) (A1,B0), and
+//              only one new register sub-tile is read from LDS per phase (8+4, 4, 8, 0 ds_read_b128).
+//   ring       8 half-tile slots = 128 KiB LDS; half-tile j = 4*kt + which lives in slot j % 8.  Phase q issues the
+//              DMA (2 x buffer_load ... lds per lane) of half-tile q+6, then waits vmcnt(8): everything phase q+1 reads
+//              has landed in every wave before the barrier that separates the two phases.  The slot written by phase q
+//              was last read in phase q-2 (A0) or earlier, two barriers back even for the lagging wave group.
+//   ping-pong  each phase is  [reads, DMA issue, vmcnt] barrier [16 MFMA at raised priority] barrier ; the wm==1 waves
+//              run one barrier behind the wm==0 waves (one extra s_barrier up front, one extra for wm==0 at the end),
+//              so on every SIMD one wave issues MFMAs while the other reads fragments and issues DMA.
+//   epilogue   wave-private LDS staging (rounds of 32 rows x 64 cols fp32), row-major read-back, shared fused epilogue.
 //
-// Results at BASELINE cfg #2 shapes (gpurun_out/call18, call19): best steady state of all variants (K=3072 forward
-// 903 TFLOP/s vs 871 for 128x128) but WORSE on the K=768 problems (430-490 vs 490-680 TFLOP/s): only 222-888 tiles for
-// 256 CUs at one workgroup per CU, so the prologue latency, the 12-stage loop and the large epilogue are fully
-// exposed.  Variants tried on the way, all correct and all <= the 128x128 family here: 64-byte-row 4-stage ring;
-// 256x128 3-stage ring with counted vmcnt; the same with two wave groups staggered by half a sub-step.
-// Next step (not built): persistent tile loop (prefetch the next tile's first stage under the epilogue) + producer
-// wave so the MFMA waves never pay the DMA issue cost.
+// History of this file (all variants were correct; numbers at BASELINE cfg #2 shapes): a plain 2-stage 256x256 loop
+// (vmcnt(0) + barrier per 64 KiB stage) reached 903 TFLOP/s at K=3072 but 430-490 at K=768; 64-byte-row 4-stage ring,
+// 256x128 3-stage ring with counted vmcnt, and a coarse half-sub-step stagger were all <= the 128x128 family.
 //
-// Tile images are the 128x128 family's (gemm.hip) with more rows; XOR swizzles are applied to the per-lane GLOBAL
-// source address of the lane-linear DMA:
-//   k-contiguous [R rows][128 B]:     chunk' = chunk ^ (((row>>1)&3)<<1)
-//   k-strided bf16 [64 k][R*2 B]:     32-byte block' = block ^ ((k&3) | ((k>>3)&1)<<2)   (ds_read_b64_tr_b16)
-//   k-strided f32  [32 k][R*4 B]:     col' = col ^ (((k>>2)&1)<<4)                       (ds_read_b32)
+// LDS images (XOR swizzles are applied to the per-lane GLOBAL source address of the lane-linear DMA):
+//   k-contiguous half [128 rows][128 B]:  chunk' = chunk ^ (((row>>1)&3)<<1)
+//   k-strided    half [64 k][256 B]:      32-byte block' = block ^ ((k&3) | ((k>>3)&1)<<2)   (ds_read_b64_tr_b16)
 #include "common.h"
 #include "gemm_common.h"
 #include <stdlib.h>
@@ -33,74 +35,70 @@ namespace {
 
 using namespace xpgemm;
 
-constexpr int TM = 256, TN = 256, SKB = 128;     // SKB: bytes of k per stage
-constexpr int NTH = 512, NWAVES = 8, NS = 2;
-constexpr int WAVES_N = 4, MT = TM / (NWAVES / WAVES_N) / 16, NT = TN / WAVES_N / 16;   // wave tile 128 x 64: 8 x 4
-constexpr int A_BYTES = TM * SKB, B_BYTES = TN * SKB;
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KiB
-constexpr int LPS = (A_BYTES + B_BYTES) / (NTH * 16);   // DMA instructions per thread per stage = 6
+typedef bf16_t T;
+constexpr int TM = 256, TN = 256, SKB = 128, KE = 64;   // SKB: bytes of k per k-tile
+constexpr int NTH = 512, NWAVES = 8;
+constexpr int WAVES_N = 4, MT = 8, NT = 4;               // wave tile 128 x 64
+constexpr int HALF_ROWS = 128, HALF_BYTES = HALF_ROWS * SKB, NSLOT = 8, LDS_BYTES = NSLOT * HALF_BYTES;
 
 typedef __attribute__((address_space(3))) char lds_char;
 
-// R = rows of the operand tile (256 for the M side, 128 for the N side)
-template <typename T, bool KS, int R>
-struct Stager {
-  static constexpr int ES = sizeof(T);
-  static constexpr int KE = SKB / ES;
-  static constexpr int NPASS = R * SKB / 1024 / NWAVES;      // 1 KiB DMA passes per wave per stage: 4 (R=256) / 2
-  static constexpr int RB = R * ES;                          // bytes of one k-row of the k-strided image
-  static constexpr int LPR = RB / 16;                        // lanes per k-row
+// DMA of one operand's half-tiles.  SUB = rows of one wave in a half (64 on the M side, 32 on the N side):
+// local row r of half h is tile row (r / SUB) * 2 * SUB + h * SUB + r % SUB.
+template <bool KS, int SUB>
+struct HalfStager {
   __amdgpu_buffer_rsrc_t rsrc;
-  unsigned voff[NPASS];
+  unsigned voff[2][2];     // [half][pass]
   unsigned step;
-  unsigned lds_off[NPASS];
+  unsigned lds_off[2];
+
+  static __device__ __forceinline__ int tile_row(int r, int h) { return (r / SUB) * (2 * SUB) + h * SUB + (r % SUB); }
 
   __device__ __forceinline__ void init(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t kend, int64_t kbeg,
                                        int lane, int wave) {
-    const int64_t bytes = (KS ? kend : rows) * ld * ES;
+    const int64_t bytes = (KS ? kend : rows) * ld * 2;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (unsigned)bytes, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NPASS; ++j) {
-      const int pass = j * NWAVES + wave;
+    for (int j = 0; j < 2; ++j) {
+      const int pass = j * NWAVES + wave;        // 16 passes of 1 KiB per half-tile
       lds_off[j] = pass * 1024;
-      int64_t off;
-      if constexpr (!KS) {
-        const int row = pass * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ swz128(row);
-        off = ((row0 + row) * ld + kbeg) * ES + c * 16;
-      } else if constexpr (sizeof(T) == 2) {
-        const int kr = pass * (64 / LPR) + lane / LPR, c16 = lane % LPR;
-        const int src = (((c16 >> 1) ^ ks_f(kr)) << 1) | (c16 & 1);
-        off = ((kbeg + kr) * ld + row0) * ES + src * 16;
-      } else {
-        const int kr = pass * (64 / LPR) + lane / LPR;
-        const int col = ((lane % LPR) * 4) ^ (((kr >> 2) & 1) << 4);
-        off = ((kbeg + kr) * ld + row0 + col) * ES;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t off;
+        if constexpr (!KS) {
+          const int row = pass * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ swz128(row);
+          off = ((row0 + tile_row(row, h)) * ld + kbeg) * 2 + c * 16;
+        } else {
+          const int kr = pass * 4 + (lane >> 4), c16 = lane & 15;
+          const int src = (((c16 >> 1) ^ ks_f(kr)) << 1) | (c16 & 1);
+          off = ((kbeg + kr) * ld + row0 + tile_row(src * 8, h)) * 2;
+        }
+        voff[h][j] = off >= bytes ? 0xFFFFFFF0u : (unsigned)off;
       }
-      voff[j] = off >= bytes ? 0xFFFFFFF0u : (unsigned)off;
     }
-    step = (unsigned)((KS ? (int64_t)KE * ld : (int64_t)KE) * ES);
+    step = (unsigned)((KS ? (int64_t)KE * ld : (int64_t)KE) * 2);
   }
-  __device__ __forceinline__ void issue(char* tile, int kt) const {
-    lds_char* t3 = (lds_char*)tile;
+  __device__ __forceinline__ void issue(char* slot, int h, int kt) const {
+    lds_char* t3 = (lds_char*)slot;
     const unsigned adv = (unsigned)kt * step;
 #pragma unroll
-    for (int j = 0; j < NPASS; ++j) {
-      unsigned o = voff[j] + adv;
-      if (o < voff[j]) o = 0xFFFFFFF0u;
+    for (int j = 0; j < 2; ++j) {
+      unsigned o = voff[h][j] + adv;
+      if (o < voff[h][j]) o = 0xFFFFFFF0u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, t3 + lds_off[j], 16, o, 0, 0, 0);
     }
   }
 };
 
-// fragment of 16-row sub-tile `ot` for the 64-byte k super-step `ks` (0..1) of a stage
-template <typename T, bool KS, int R>
-__device__ __forceinline__ typename Frag<T>::type frag(const char* tile, int ot, int ks, int lane) {
-  constexpr int RB = R * (int)sizeof(T);
+// fragment of local 16-row sub-tile `ot` (0..7) of a half-tile for the 32-element k sub-step `ks` (0..1)
+template <bool KS>
+__device__ __forceinline__ bf16x8 frag(const char* tile, int ot, int ks, int lane) {
+  constexpr int RB = HALF_ROWS * 2;
   const int i = lane & 15, g = lane >> 4;
   if constexpr (!KS) {
-    return *reinterpret_cast<const typename Frag<T>::type*>(tile + tile128_off(ot * 16 + i, ks * 4 + g));
-  } else if constexpr (sizeof(T) == 2) {
+    return *reinterpret_cast<const bf16x8*>(tile + tile128_off(ot * 16 + i, ks * 4 + g));
+  } else {
     const int f = (i >> 2) | ((g & 1) << 2);
     const int kr = ks * 32 + g * 8 + (i >> 2);
     const char* p = tile + kr * RB + ((ot ^ f) << 5) + ((i & 3) << 3);
@@ -109,18 +107,12 @@ __device__ __forceinline__ typename Frag<T>::type frag(const char* tile, int ot,
     typedef __attribute__((ext_vector_type(8))) short i16x8;
     i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
-  } else {
-    f32x4 v;
-    const int col = (ot * 16 + i) ^ ((g & 1) << 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const float*>(tile + (ks * 16 + 4 * g + e) * RB + col * 4);
-    return v;
   }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, bool AKS, bool BKS>
+template <bool AKS, bool BKS>
 __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -128,22 +120,19 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int bid = xcd_remap(blockIdx.x, nwg, p.xcd_remap);
   int tm, tn;
   tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
   const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
 
-  constexpr int KE = SKB / sizeof(T);
   const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
-  const int nk = (int)((kend - kbeg + KE - 1) / KE);
+  const int nk = (int)((kend - kbeg + KE - 1) / KE);       // >= 2 (launcher)
 
-  Stager<T, AKS, TM> ga;
-  Stager<T, BKS, TN> gb;
+  HalfStager<AKS, 64> ga;
+  HalfStager<BKS, 32> gb;
   ga.init(reinterpret_cast<const T*>(p.A), p.lda, m0, p.M, kend, kbeg, lane, wave);
   gb.init(reinterpret_cast<const T*>(p.B), p.ldb, n0, p.N, kend, kbeg, lane, wave);
-  auto slotA = [&](int s) -> char* { return smem + s * STAGE_BYTES; };
-  auto slotB = [&](int s) -> char* { return smem + s * STAGE_BYTES + A_BYTES; };
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -153,63 +142,87 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 
   const bool trace = p.dbg != nullptr && (int)blockIdx.x == nwg / 2 && blockIdx.z == 0 && wave == 0;
   unsigned long long* tr = p.dbg;
-#define XP_STAMP(i) do { if (trace && t < 24) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) tr[8 + t * 5 + (i)] = t_; } } while (0)
   if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
-  // prologue: NS-1 stages in flight
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) { ga.issue(slotA(s), s); gb.issue(slotB(s), s); }
 
-  int slot = 0;
-  for (int t = 0; t < nk; ++t) {
-    XP_STAMP(0);
-    // stages issued so far = min(nk, t+NS-1); stage t must have landed -> the younger one may stay in flight
-    if (NS > 2 && t + 1 < nk) wait_vmcnt<(NS - 2) * LPS>(); else wait_vmcnt<0>();
-    XP_STAMP(1);
-    __builtin_amdgcn_s_barrier();
-    XP_STAMP(2);
-    if (t + NS - 1 < nk) {
-      const int s2 = slot == 0 ? NS - 1 : slot - 1;          // (t + NS - 1) % NS == (t - 1) % NS
-      ga.issue(slotA(s2), t + NS - 1);
-      gb.issue(slotB(s2), t + NS - 1);
-    }
-    XP_STAMP(3);
-    const char* tA = slotA(slot);
-    const char* tB = slotB(slot);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      typename Frag<T>::type fw[NT], fx[MT];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) fw[i] = frag<T, BKS, TN>(tB, wn * NT + i, ks, lane);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fx[i] = frag<T, AKS, TM>(tA, wm * MT + i, ks, lane);
-      __builtin_amdgcn_sched_barrier(0);      // all fragment reads in flight before the first MFMA (no read/wait/MFMA ping-pong)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mma16(fw[nt], fx[mt], acc[nt][mt]);
-    }
-    XP_STAMP(4);
-    slot = slot == NS - 1 ? 0 : slot + 1;
-  }
-#undef XP_STAMP
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();        // every wave is done reading the ring -> LDS is free for the epilogue
+  // slot of half-tile `which` (0:A0 1:B0 2:B1 3:A1) of k-tile kt
+  auto slot = [&](int kt, int which) -> char* { return smem + (((kt & 1) << 2) + which) * HALF_BYTES; };
+
+  // prologue: half-tiles 0..5 in flight; 0 and 1 landed everywhere before the first phase
+  ga.issue(slot(0, 0), 0, 0); gb.issue(slot(0, 1), 0, 0); gb.issue(slot(0, 2), 1, 0); ga.issue(slot(0, 3), 1, 0);
+  ga.issue(slot(1, 0), 0, 1); gb.issue(slot(1, 1), 0, 1);
+  wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();       // the wm==1 group runs one barrier behind
+
+  bf16x8 fa[2][4], fb[2][2][2];                     // fa[ks][mt] (current A half), fb[hB][ks][nt]
+
+#define XP_PHASE_MMA(HA, HB)                                                                          \
+  do {                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                              \
+          acc[(HB) * 2 + nt][(HA) * 4 + mt] = mma16(fb[HB][ks][nt], fa[ks][mt], acc[(HB) * 2 + nt][(HA) * 4 + mt]); \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_barrier();                                                                     \
+  } while (0)
+#define XP_READ_A(TILE)                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) fa[ks][mt] = frag<AKS>(TILE, wm * 4 + mt, ks, lane)
+#define XP_READ_B(HB, TILE)                                                                           \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) fb[HB][ks][nt] = frag<BKS>(TILE, wn * 2 + nt, ks, lane)
+
+  // One k-tile = 4 phases.  TAIL 0: steady state, 1: k-tile nk-2, 2: k-tile nk-1 (fewer half-tiles left to issue/await).
+  auto ktile = [&](int t, auto tail_c) {
+    constexpr int TAIL = decltype(tail_c)::value;
+    // ---- phase 0: (A0, B0) ----
+    XP_READ_B(0, slot(t, 1));
+    __builtin_amdgcn_sched_barrier(0);
+    XP_READ_A(slot(t, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAIL <= 1) gb.issue(slot(t + 1, 2), 1, t + 1);
+    wait_vmcnt<(TAIL <= 1 ? 8 : 2)>();
+    XP_PHASE_MMA(0, 0);
+    // ---- phase 1: (A0, B1) ----
+    XP_READ_B(1, slot(t, 2));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAIL <= 1) ga.issue(slot(t + 1, 3), 1, t + 1);
+    wait_vmcnt<(TAIL <= 1 ? 8 : 0)>();
+    XP_PHASE_MMA(0, 1);
+    // ---- phase 2: (A1, B1) ----
+    XP_READ_A(slot(t, 3));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAIL == 0) ga.issue(slot(t, 0), 0, t + 2);
+    wait_vmcnt<(TAIL == 0 ? 8 : (TAIL == 1 ? 6 : 0))>();
+    XP_PHASE_MMA(1, 1);
+    // ---- phase 3: (A1, B0) ----
+    if constexpr (TAIL == 0) gb.issue(slot(t, 1), 0, t + 2);
+    wait_vmcnt<(TAIL == 0 ? 8 : (TAIL == 1 ? 4 : 0))>();
+    XP_PHASE_MMA(1, 0);
+  };
+  for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
+  ktile(nk - 2, std::integral_constant<int, 1>{});
+  ktile(nk - 1, std::integral_constant<int, 2>{});
+#undef XP_PHASE_MMA
+#undef XP_READ_A
+#undef XP_READ_B
+  if (wm == 0) __builtin_amdgcn_s_barrier();       // re-align the two wave groups
+  __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring -> LDS is free for the epilogue
   if (trace && lane == 0) tr[2] = __builtin_amdgcn_s_memtime();
 
-  // ---- epilogue: wave-private staging, MT/2 rounds of 32 rows x (NT*16) columns --------------------------------
-  constexpr int CW = NT * 16, CCH = CW / 4;                 // staged columns per wave, 16-byte chunks per row
+  // ---- epilogue: wave-private staging, MT/2 rounds of 32 rows x 64 columns fp32 ------------------------------------
+  constexpr int CW = NT * 16;
   char* stg = smem + wave * (32 * CW * 4);
   const int i16 = lane & 15, g = lane >> 4;
-  const int c = lane % CCH, r4 = lane / CCH;                // read-back: CCH lanes per row, 64/CCH rows per pass
-  const int64_t n = n0 + wn * CW + c * 4;
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
-  const bool ncol_ok = n < p.N;
-  const EpiLane el(p, ncol_ok ? n : 0);
-#pragma unroll
-  for (int q = 0; q < MT / 2; ++q) {
+  auto stage_round = [&](int q) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = h * 16 + i16;
@@ -218,73 +231,135 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
         *reinterpret_cast<f32x4*>(stg + row * (CW * 4) + (((nt * 4 + g) ^ (row & 7)) << 4)) = acc[nt][q * 2 + h];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c) {
+    constexpr int EPI = decltype(epi_c)::value;
+    constexpr bool F32 = decltype(f32_c)::value;
+    const int c = lane & 7, r8 = lane >> 3;           // 8 columns per lane: 8 lanes per row, 8 rows per pass
+    const FastEpi<T, EPI, F32> fe(p, F32 ? (void*)Cf : (void*)Ct, n0 + wn * CW + c * 8);
+    const unsigned mrow = (unsigned)(m0 + wm * (MT * 16)) + r8;
+    Raw8<T> pre[2][4];
+    if constexpr (EpiTraits<EPI>::pre) {
 #pragma unroll
-    for (int pass = 0; pass < 32 / (64 / CCH); ++pass) {
-      const int row = pass * (64 / CCH) + r4;
-      const int64_t m = m0 + wm * (MT * 16) + q * 32 + row;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + ((c ^ (row & 7)) << 4));
-      if (ncol_ok && m < p.M) epi_row<T>(p, el, v, m, n, Cf, Ct);
+      for (int pass = 0; pass < 4; ++pass) pre[0][pass] = fe.load_pre(mrow + pass * 8);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < MT / 2; ++q) {
+      if constexpr (EpiTraits<EPI>::pre) {
+        if (q + 1 < MT / 2) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) pre[(q + 1) & 1][pass] = fe.load_pre(mrow + (q + 1) * 32 + pass * 8);
+        }
+      }
+      stage_round(q);
+      f32x8 v[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + r8;
+        v[pass].lo = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c) ^ (row & 7)) << 4));
+        v[pass].hi = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c + 1) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) fe.finish(v[pass], pre[q & 1][pass], mrow + q * 32 + pass * 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  });
+  if (fast) {
+  } else if (p.wide) {                              // 8 columns per lane: 8 lanes per row, 8 rows per pass
+    const int c = lane & 7, r8 = lane >> 3;
+    const int64_t n = n0 + wn * CW + c * 8;
+    const bool ncol_ok = n < p.N;
+    const EpiLane8 el(p, ncol_ok ? n : 0);
+#pragma unroll
+    for (int q = 0; q < MT / 2; ++q) {
+      stage_round(q);
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + r8;
+        const int64_t m = m0 + wm * (MT * 16) + q * 32 + row;
+        f32x8 v;
+        v.lo = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c) ^ (row & 7)) << 4));
+        v.hi = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c + 1) ^ (row & 7)) << 4));
+        if (ncol_ok && m < p.M) epi_row8<T>(p, el, v, m, n, Cf, Ct);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    const int c = lane & 15, r4 = lane >> 4;
+    const int64_t n = n0 + wn * CW + c * 4;
+    const bool ncol_ok = n < p.N;
+    const EpiLane el(p, ncol_ok ? n : 0);
+#pragma unroll
+    for (int q = 0; q < MT / 2; ++q) {
+      stage_round(q);
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 4 + r4;
+        const int64_t m = m0 + wm * (MT * 16) + q * 32 + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + ((c ^ (row & 7)) << 4));
+        if (ncol_ok && m < p.M) epi_row<T>(p, el, v, m, n, Cf, Ct);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
   if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
 }
 
-template <typename T, bool AKS, bool BKS>
+template <bool AKS, bool BKS>
 void launch_one(const KParams& kp, dim3 grid, hipStream_t st) {
   static bool configured = false;
-  auto kern = gemm256_kernel<T, AKS, BKS>;
+  auto kern = gemm256_kernel<AKS, BKS>;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     configured = true;
   }
-  kern<<<grid, NTH, NS * STAGE_BYTES, st>>>(kp);
-}
-
-template <typename T>
-void launch_t(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
-  if (!d->a_kstrided && !d->b_kstrided)      launch_one<T, false, false>(kp, grid, st);
-  else if (!d->a_kstrided && d->b_kstrided)  launch_one<T, false, true>(kp, grid, st);
-  else if (d->a_kstrided && d->b_kstrided)   launch_one<T, true, true>(kp, grid, st);
-  else                                       launch_one<T, true, false>(kp, grid, st);
+  kern<<<grid, NTH, LDS_BYTES, st>>>(kp);
 }
 
 // explicit instantiations (hipcc otherwise drops the host stubs of the k-strided variants)
-#define XP_INST(T) \
-  template __global__ void gemm256_kernel<T, false, false>(KParams); \
-  template __global__ void gemm256_kernel<T, false, true>(KParams);  \
-  template __global__ void gemm256_kernel<T, true, true>(KParams);   \
-  template __global__ void gemm256_kernel<T, true, false>(KParams);
-XP_INST(bf16_t)
-XP_INST(float)
-#undef XP_INST
+template __global__ void gemm256_kernel<false, false>(KParams);
+template __global__ void gemm256_kernel<false, true>(KParams);
+template __global__ void gemm256_kernel<true, true>(KParams);
+template __global__ void gemm256_kernel<true, false>(KParams);
 
 }  // namespace
 
-bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st) {
-  // 0 = off (default), 1 = size heuristic, 2 = whenever legal (see the header comment for the measurements).
-  const char* env = getenv("XPRETRAIN_GEMM256");
-  const int mode = env ? atoi(env) : 0;
-  if (mode == 0) return false;
-  const int esz = d->in_dtype == XP_BF16 ? 2 : 4;
-  const int64_t ke = SKB / esz;
-  if (d->a_grp != 0) return false;
-  if (mode == 1 && (d->M < 1024 || d->N < 256 || d->K < 4 * ke)) return false;   // small problems: 128x128 family
+// preconditions of the family that do not depend on split_k
+bool xp_gemm256_legal(const XpGemmDesc* d) {
+  if (d->in_dtype != XP_BF16 || d->a_grp != 0) return false;
   const int64_t a_rows = d->a_kstrided ? d->K : d->M, b_rows = d->b_kstrided ? d->K : d->N;
-  if (!d->a_kstrided && (d->K % ke != 0 || d->lda != d->K)) return false;
-  if (!d->b_kstrided && (d->K % ke != 0 || d->ldb != d->K)) return false;
+  if (!d->a_kstrided && (d->K % KE != 0 || d->lda != d->K)) return false;
+  if (!d->b_kstrided && (d->K % KE != 0 || d->ldb != d->K)) return false;
   if (d->a_kstrided && (d->M % TM != 0 || d->lda != d->M)) return false;
   if (d->b_kstrided && (d->N % TN != 0 || d->ldb != d->N)) return false;
   const int64_t lim = (int64_t)0xFFFFFFF0u - 512 * 1024 * 1024;
-  if ((a_rows + TM) * d->lda * esz >= lim || (b_rows + TN) * d->ldb * esz >= lim) return false;
+  if ((a_rows + TM) * d->lda * 2 >= lim || (b_rows + TN) * d->ldb * 2 >= lim) return false;
+  return true;
+}
+
+// XPRETRAIN_GEMM256: 0 = never, 1 = when it fills at least half the CUs (default), 2 = whenever legal.
+bool xp_gemm256_wanted(const XpGemmDesc* d, int split) {
+  const char* env = getenv("XPRETRAIN_GEMM256");
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || !xp_gemm256_legal(d)) return false;
+  if (mode == 1 && cdiv(d->M, TM) * cdiv(d->N, TN) * split < 128) return false;
+  return true;
+}
+
+bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st) {
   const int split = d->split_k > 1 ? d->split_k : 1;
+  if (!xp_gemm256_wanted(d, split)) return false;
   xpgemm::KParams kp = kp_base;
-  kp.k_per_split = cdiv(cdiv(d->K, split), ke) * ke;
+  kp.k_per_split = cdiv(cdiv(d->K, split), KE) * KE;
   if (split > 1 && cdiv(d->K, kp.k_per_split) != split) return false;
+  const int64_t k_last = d->K - (int64_t)(split - 1) * kp.k_per_split;
+  if (cdiv(k_last, KE) < 2) return false;                                         // the pipeline needs >= 2 k-tiles
   kp.tiles_m = (int)cdiv(d->M, TM); kp.tiles_n = (int)cdiv(d->N, TN);
-  kp.group_n = kp.tiles_n; kp.xcd_remap = 1;
+  kp.group_n = kp.tiles_n;
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
-  if (d->in_dtype == XP_BF16) launch_t<bf16_t>(d, kp, grid, st);
-  else                        launch_t<float>(d, kp, grid, st);
+  if (!d->a_kstrided && !d->b_kstrided)      launch_one<false, false>(kp, grid, st);
+  else if (!d->a_kstrided && d->b_kstrided)  launch_one<false, true>(kp, grid, st);
+  else if (d->a_kstrided && d->b_kstrided)   launch_one<true, true>(kp, grid, st);
+  else                                       launch_one<true, false>(kp, grid, st);
   return true;
 }

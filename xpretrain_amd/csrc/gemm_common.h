@@ -1,6 +1,7 @@
 // Shared between the GEMM kernel families (gemm.hip: 128x128 tiles; gemm256.hip: 256x256 deep-pipelined tiles).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace xpgemm {
 
@@ -25,6 +26,7 @@ struct KParams {
   int group_n;               // tile columns per L2 super-tile group (see tile_of)
   int xcd_remap;             // 1: consecutive tile ids -> same XCD (default); 0: hardware round-robin (A/B switch)
   int wide;                  // 1: N, ldc, ldr, ldaux all multiples of 8 -> 8 columns per lane, 16-byte bf16 stores
+  int fast_epi;              // 1: wide, identity cmap, C / resid / aux each < 4 GiB -> branch-free buffer-addressed epilogue
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
 
@@ -100,6 +102,120 @@ __device__ __forceinline__ void epi_row8(const KParams& p, const EpiLane8& el, f
   else           store8(Ct + crow * p.ldc + n, v);
 }
 
+// ---- fast epilogue -----------------------------------------------------------------------------------------------------
+// The generic epi_row/epi_row8 above branch on the run-time epilogue kind and on row predicates inside every unrolled
+// pass; hipcc's waitcnt insertion then falls back to `s_waitcnt vmcnt(0)` at the block joins, i.e. every pass waits for
+// the previous pass's STORES to be acknowledged (measured: 18k cycles for a 256x256 tile, ~1.1k per pass).  The fast
+// path is straight-line code per epilogue kind: buffer-addressed accesses whose hardware bounds check drops rows >= M
+// (and lanes past N, whose offset is forced out of range), residual / pre-activation loads issued one round ahead of
+// the stores that would otherwise sit in front of them in the in-order vmcnt queue.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr unsigned EPI_OOB = 0xFFFFFF00u;     // + 16 (second half of a 32-byte access) must not wrap
+
+template <int EPI> struct EpiTraits {
+  static constexpr bool bias = EPI == XP_EPI_BIAS || EPI == XP_EPI_BIAS_QSCALE || EPI == XP_EPI_BIAS_GELU || EPI == XP_EPI_BIAS_RESID;
+  static constexpr bool scale = EPI == XP_EPI_BIAS_QSCALE || EPI == XP_EPI_SCALE;
+  static constexpr bool pre = EPI == XP_EPI_BIAS_RESID || EPI == XP_EPI_GELU_BWD;     // needs an [M, N] side input
+};
+
+template <typename T, bool F32>
+__device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned off, const f32x8& v) {
+  if constexpr (F32 || sizeof(T) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v.lo), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v.hi), r, off + 16, 0, 0);
+  } else {
+    bf16x8 o = {(bf16_t)v.lo[0], (bf16_t)v.lo[1], (bf16_t)v.lo[2], (bf16_t)v.lo[3],
+                (bf16_t)v.hi[0], (bf16_t)v.hi[1], (bf16_t)v.hi[2], (bf16_t)v.hi[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r, off, 0, 0);
+  }
+}
+// raw 8-element side input of type T (converted at use, so the load can stay in flight)
+template <typename T> struct Raw8 { u32x4 a, b; };
+template <typename T>
+__device__ __forceinline__ Raw8<T> bload8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  Raw8<T> x;
+  x.a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  if constexpr (sizeof(T) == 4) x.b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ f32x8 raw8_f32(const Raw8<T>& x) {
+  if constexpr (sizeof(T) == 4) return f32x8{__builtin_bit_cast(f32x4, x.a), __builtin_bit_cast(f32x4, x.b)};
+  else {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, x.a);
+    return f32x8{f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
+  }
+}
+
+// Per-wave state of the fast epilogue; the lane owns columns n .. n+7.
+template <typename T, int EPI, bool F32>
+struct FastEpi {
+  using Tr = EpiTraits<EPI>;
+  static constexpr unsigned OSZ = F32 ? 4 : sizeof(T);
+  __amdgpu_buffer_rsrc_t rc, rx;
+  f32x8 bias; float cs_lo, cs_hi;
+  unsigned ld_c, ld_x;      // row pitch in bytes
+  unsigned col_c, col_x;    // byte offset of column n
+  bool ok;
+  __device__ __forceinline__ FastEpi(const KParams& p, void* Cbase, int64_t n) {
+    ok = n < p.N;
+    const int64_t nn = ok ? n : 0;
+    rc = __builtin_amdgcn_make_buffer_rsrc(Cbase, 0, (unsigned)(p.M * p.ldc * OSZ), 0x00020000);
+    ld_c = (unsigned)(p.ldc * OSZ); col_c = (unsigned)(nn * OSZ);
+    if constexpr (EPI == XP_EPI_BIAS_GELU) {
+      rx = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, (unsigned)(p.M * p.ldaux * OSZ), 0x00020000);
+      ld_x = (unsigned)(p.ldaux * OSZ); col_x = (unsigned)(nn * OSZ);
+    } else if constexpr (Tr::pre) {
+      rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0, (unsigned)(p.M * p.ldr * sizeof(T)), 0x00020000);
+      ld_x = (unsigned)(p.ldr * sizeof(T)); col_x = (unsigned)(nn * sizeof(T));
+    } else { rx = rc; ld_x = 0; col_x = 0; }
+    if constexpr (Tr::bias) bias = f32x8{load4(p.bias + nn), load4(p.bias + nn + 4)};
+    if constexpr (EPI == XP_EPI_SCALE) cs_lo = cs_hi = p.scale;
+    if constexpr (EPI == XP_EPI_BIAS_QSCALE) { cs_lo = nn < p.scale_cols ? p.scale : 1.f; cs_hi = nn + 4 < p.scale_cols ? p.scale : 1.f; }
+  }
+  __device__ __forceinline__ unsigned off_c(unsigned m) const { return ok ? m * ld_c + col_c : EPI_OOB; }
+  __device__ __forceinline__ unsigned off_x(unsigned m) const { return ok ? m * ld_x + col_x : EPI_OOB; }
+  __device__ __forceinline__ Raw8<T> load_pre(unsigned m) const { return bload8<T>(rx, off_x(m)); }
+  __device__ __forceinline__ void finish(f32x8 v, const Raw8<T>& pre, unsigned m) const {
+    if constexpr (Tr::bias) { v.lo += bias.lo; v.hi += bias.hi; }
+    if constexpr (Tr::scale) { v.lo *= cs_lo; v.hi *= cs_hi; }
+    if constexpr (EPI == XP_EPI_BIAS_GELU) {
+      bstore8<T, F32>(rx, off_x(m), v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
+    } else if constexpr (EPI == XP_EPI_BIAS_RESID) {
+      const f32x8 r = raw8_f32<T>(pre);
+      v.lo += r.lo; v.hi += r.hi;
+    } else if constexpr (EPI == XP_EPI_GELU_BWD) {
+      const f32x8 r = raw8_f32<T>(pre);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v.lo[e] *= quick_gelu_grad_f(r.lo[e]); v.hi[e] *= quick_gelu_grad_f(r.hi[e]); }
+    }
+    bstore8<T, F32>(rc, off_c(m), v);
+  }
+};
+
+// Calls f(integral_constant<int, EPI>, bool_constant<F32>) for the (epilogue, output type) pairs the fast path
+// specialises; returns false for any other pair (the caller then runs the generic epilogue).
+template <typename F>
+__device__ __forceinline__ bool fast_epi_dispatch(const KParams& p, F&& f) {
+  using std::integral_constant; using std::bool_constant;
+  if (!p.fast_epi) return false;
+  if (p.out_f32) {
+    if (p.epilogue == XP_EPI_NONE) { f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<true>{}); return true; }
+    return false;
+  }
+  switch (p.epilogue) {
+    case XP_EPI_NONE:        f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS:        f(integral_constant<int, XP_EPI_BIAS>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS_QSCALE: f(integral_constant<int, XP_EPI_BIAS_QSCALE>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS_GELU:   f(integral_constant<int, XP_EPI_BIAS_GELU>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS_RESID:  f(integral_constant<int, XP_EPI_BIAS_RESID>{}, bool_constant<false>{}); return true;
+    case XP_EPI_GELU_BWD:    f(integral_constant<int, XP_EPI_GELU_BWD>{}, bool_constant<false>{}); return true;
+    default: return false;
+  }
+}
+
 __device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 // XCD-aware bijective remap of the linear workgroup id (block b runs on XCD b % 8): consecutive tile ids -- which
@@ -128,3 +244,5 @@ __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int gr
 
 // launcher of the 256x256 family (gemm256.hip); returns false if the problem does not fit its preconditions
 bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st);
+bool xp_gemm256_legal(const XpGemmDesc* d);
+bool xp_gemm256_wanted(const XpGemmDesc* d, int split);

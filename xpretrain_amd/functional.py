@@ -88,17 +88,21 @@ class WeightCache:
 WEIGHTS = WeightCache()
 
 
-def _split_for(tiles: int, k: int) -> int:
-    """split-K factor for the weight-gradient GEMMs: fill ~one resident wave of workgroups (256 CUs x 2)."""
-    if tiles >= 256:
-        return 1
-    return max(1, min(512 // tiles, k // 512))
+_SPLITS = {}
+
+
+def _split_for(n_out: int, n_in: int, rows: int, dtype: torch.dtype, a_remap) -> int:
+    """split-K factor for the weight-gradient GEMMs (kernel-family aware, decided by the library; memoised)."""
+    key = (n_out, n_in, rows, dtype, a_remap)
+    s = _SPLITS.get(key)
+    if s is None:
+        s = _SPLITS[key] = H.gemm_auto_split(n_out, n_in, rows, dtype, lda=n_out, ldb=n_in, a_remap=a_remap)
+    return s
 
 
 def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, a_remap=(0, 0, 0)) -> torch.Tensor:
     """dW[n_out, n_in] = dY[rows, n_out]^T . X[rows, n_in] in fp32 (both operands read k-strided, split-K)."""
-    tiles = ((n_out + 127) // 128) * ((n_in + 127) // 128)
-    split = _split_for(tiles, rows)
+    split = _split_for(n_out, n_in, rows, dy.dtype, tuple(a_remap))
     dw = torch.empty((n_out, n_in), dtype=torch.float32, device=dy.device)
     if split == 1:
         H.gemm(dy, x, n_out, n_in, rows, a_kstrided=True, b_kstrided=True, lda=n_out, ldb=n_in, out=dw,
