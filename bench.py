@@ -126,11 +126,14 @@ def main():
     D.broadcast_parameters(model)
     loss_fn = NCELearnableTempLoss()
     reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True)
-    decay = [p for n, p in model.named_parameters() if p.dim() >= 2 and "logit_scale" not in n]
-    no_decay = [p for n, p in model.named_parameters() if not (p.dim() >= 2 and "logit_scale" not in n)]
     use_graph = a.graph == 1
-    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=5e-6, betas=(0.9, 0.98), eps=1e-6, fused=True, capturable=use_graph)
+    # pretrain_vip_base_16.json:68-80: adamw, betas (0.9, 0.98), lr 5e-6, wd 0.05, lr_mul 1, cosine decay with 1 % warmup,
+    # grad_norm 5.0; grouping = optimization/utils.py:124-154
+    from xpretrain_amd.optimization import AdamW, get_lr_sched, build_e2e_optimizer_w_lr_mul
+    LR, TOTAL_STEPS = 5e-6, 100000
+    groups = build_e2e_optimizer_w_lr_mul(list(model.named_parameters()), LR, 0.05, lr_mul=1, lr_mul_prefix="")
+    opt = AdamW([g for g in groups if g["params"]], lr=LR, betas=(0.9, 0.98))
+    sched_step = [1000]      # start past the warmup so the synthetic loss moves
     video, ids, mask = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank)
     video, ids, mask = video.to(dev), ids.to(dev), mask.to(dev)
     logit_scale = model.clipmodel.logit_scale
@@ -144,8 +147,11 @@ def main():
         loss = loss_fn(vis, txt, logit_scale)
         loss.backward()
         reducer.synchronize()
-        torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)        # run_pretrain.py:408-411
-        opt.step()
+        lr_t = get_lr_sched(sched_step[0], "cosine", LR, TOTAL_STEPS, warmup_ratio=0.01)   # run_video_retrieval.py:372-383
+        for g in opt.param_groups:
+            g["lr"] = lr_t
+        sched_step[0] += 1
+        opt.clip_and_step(5.0)                     # clip_grad_norm_(…, 5.0) + AdamW.step + bf16 weight copies, one pass
         reducer.zero_grad()
         return loss
 

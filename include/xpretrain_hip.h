@@ -158,6 +158,44 @@ int xp_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* 
 int xp_cast(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
 int xp_cast_back(const void* src, float* dst, int64_t n, int32_t dtype, int32_t accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------- Optimizer
+ * On-device optimizer step: torch.nn.utils.clip_grad_norm_ as the training loops call it
+ * (tasks/run_video_retrieval.py:390-392; coef = min(1, max_norm / (||g||_2 + 1e-6))) fused with AdamW.step
+ * (optimization/adamw.py:40-103: denom = sqrt(v) + eps, step_size = lr * sqrt(1-b2^t) / (1-b1^t) when
+ * correct_bias, decoupled weight decay p -= lr * wd * p AFTER the Adam update), over every parameter tensor in
+ * one launch.  fp32 masters / moments / gradients; each tensor may name a shadow copy (bf16 or f32) that is
+ * rewritten in the same pass (the compute-dtype weights the GEMMs read).  The clipped gradients themselves are
+ * NOT written back (nothing on the path reads them after the step).
+ *
+ * Work is cut into chunks of XP_OPT_CHUNK elements of one tensor; `chunk_map` holds (tensor index, chunk index)
+ * int32 pairs, one per workgroup, built once by the caller.  `table` and `chunk_map` are DEVICE arrays;
+ * `grads_host`, `group_of_host` and `groups_host` are HOST arrays (copied into the kernel-argument block, so a
+ * call takes at most XP_OPT_MAX_TENSORS tensors and XP_OPT_MAX_GROUPS hyper-parameter groups; callers with more
+ * tensors issue several calls that share one partials array). */
+#define XP_OPT_CHUNK 65536
+#define XP_OPT_MAX_TENSORS 256
+#define XP_OPT_MAX_GROUPS 16
+typedef struct {
+  void* p; void* m; void* v;            /* fp32 parameter, exp_avg, exp_avg_sq                          */
+  void* shadow;                         /* optional copy of p in shadow_dtype (NULL: none)              */
+  int64_t numel;
+  int32_t shadow_dtype;                 /* XP_BF16 / XP_F32                                             */
+  int32_t reserved;
+} XpAdamTensor;
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay;
+  float step_size;                      /* lr * sqrt(1-beta2^t) / (1-beta1^t) (or lr if !correct_bias)  */
+} XpAdamGroup;
+/* partials[c] = sum of squares of chunk c's gradient elements (fixed order, deterministic). */
+int xp_grad_sqnorm_partials(const XpAdamTensor* table, const int32_t* chunk_map, int32_t n_chunks,
+                            const void* const* grads_host, int32_t n_tensors, float* partials, void* stream);
+/* norm_partials (nullable): ALL chunks' partial sums of squares (n_norm_partials of them); max_norm <= 0: no
+ * clipping; grad_norm_out (nullable): receives ||g||_2 before clipping. */
+int xp_adamw_step(const XpAdamTensor* table, const int32_t* chunk_map, int32_t n_chunks,
+                  const void* const* grads_host, const uint8_t* group_of_host, int32_t n_tensors,
+                  const XpAdamGroup* groups_host, int32_t n_groups, const float* norm_partials,
+                  int32_t n_norm_partials, float max_norm, float* grad_norm_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------- Loss
  * NCELearnableTempLoss.forward (optimization/loss.py:134-141) on gathered unit-norm features
  * vis[n,d], txt[n,d] (fp32) and the LOG scale parameter: loss = CE(s V T^T, diag) + CE(s T V^T, diag).

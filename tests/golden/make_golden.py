@@ -19,6 +19,8 @@ Fixtures (all fp32, CPU, torch.manual_seed'ed):
   temporal_interp.pt CLIPVisionViPEmbeddings for T in {1,8,12,32} (temporal_size 12).
   loss.pt            NCELearnableTempLoss / NCELearnableTempLoss_vsc_fc for several batch sizes
                      and logit scales (incl. both clamp limits 0 and ln 200).
+  optim.pt           src/optimization: AdamW.step x 6 with clip_grad_norm_ 5.0 and the warmup-cosine schedule
+                     over the four build_e2e_optimizer_w_lr_mul groups; get_lr_sched tables.
 """
 import math
 import os
@@ -193,13 +195,59 @@ def loss(ref):
     print("loss:", len(cases))
 
 
+def optim(ref):
+    import importlib
+    import warnings
+    adamw = importlib.import_module("src.optimization.adamw")
+    sched = importlib.import_module("src.optimization.sched")
+    utils = importlib.import_module("src.optimization.utils")
+    torch.manual_seed(77)
+    names = ["clipmodel.vision_model.encoder.layers.0.mlp.fc1.weight", "clipmodel.vision_model.encoder.layers.0.mlp.fc1.bias",
+             "clipmodel.text_model.encoder.layers.0.self_attn.q_proj.weight", "clipmodel.text_model.final_layer_norm.bias",
+             "clipmodel.logit_scale", "clipmodel.visual_projection.weight", "clipmodel.vision_model.embeddings.added_cls"]
+    shapes = [(48, 33), (48,), (64, 64), (64,), (), (32, 48), (3, 37)]
+    params = [torch.nn.Parameter(torch.randn(s) * 0.05) for s in shapes]
+    init = [p.detach().clone() for p in params]
+    lr0, wd, lr_mul, steps, total = 1e-3, 0.2, 0.1, 6, 20
+    groups = utils.build_e2e_optimizer_w_lr_mul(list(zip(names, params)), lr0, wd, lr_mul=lr_mul,
+                                                lr_mul_prefix="text_model")
+    group_idx = [[[id(p) for p in params].index(id(q)) for q in g["params"]] for g in groups]
+    opt = adamw.AdamW(groups, lr=lr0, betas=(0.9, 0.98))
+    grads, norms, lrs = [], [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(steps):
+            lr_t = sched.get_lr_sched(t, "cosine", lr0, total, warmup_ratio=0.2)
+            for gi, g in enumerate(opt.param_groups):                 # run_video_retrieval.py:377-383
+                g["lr"] = lr_mul * lr_t if gi in (0, 1) else lr_t
+            gs = [torch.randn(s) * (4.0 if t % 2 == 0 else 0.03) for s in shapes]  # clip active on even steps only
+            for p, g in zip(params, gs):
+                p.grad = g.clone()
+            norms.append(torch.nn.utils.clip_grad_norm_(params, 5.0).clone())
+            opt.step()
+            grads.append(gs)
+            lrs.append(lr_t)
+    table = {d: [sched.get_lr_sched(t, d, 3e-4, 50, warmup_ratio=0.1) for t in range(0, 56)]
+             for d in ("linear", "cosine", "invsqrt", "constant")}
+    torch.save(dict(names=names, init=init, grads=grads, norms=norms, lrs=lrs, lr_mul=lr_mul, weight_decay=wd,
+                    betas=(0.9, 0.98), group_idx=group_idx, final=[p.detach().clone() for p in params],
+                    exp_avg=[opt.state[p]["exp_avg"].clone() for p in params],
+                    exp_avg_sq=[opt.state[p]["exp_avg_sq"].clone() for p in params], sched_table=table),
+               os.path.join(HERE, "optim.pt"))
+    print("optim: steps", steps, "norms", [round(float(n), 3) for n in norms])
+
+
 if __name__ == "__main__":
     ref = ref_import.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "optim":
+        optim(ref)
+        sys.exit(0)
     tiny_e2e(ref)
     attn_forward2(ref)
     text_attn(ref)
     temporal_interp(ref)
     loss(ref)
+    optim(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -13,14 +13,14 @@ def dump(name, obj):
         json.dump(obj, f)
 
 
-def maxrel(a: torch.Tensor, b: torch.Tensor) -> float:
-    """max|a-b| / max|b| (error relative to the tensor scale)."""
+def maxrel(a: torch.Tensor, b: torch.Tensor, scale_floor: float = 1e-30) -> float:
+    """max|a-b| / max(max|b|, scale_floor) (error relative to the tensor scale)."""
     a, b = a.double().cpu(), b.double().cpu()
-    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(scale_floor)).item()
 
 
-def report(tag, a, b, tol, log=None):
-    e = maxrel(a, b)
+def report(tag, a, b, tol, log=None, scale_floor: float = 1e-30):
+    e = maxrel(a, b, scale_floor)
     line = f"{tag}: maxrel={e:.3e} tol={tol:.1e} {'OK' if e <= tol else 'FAIL'}"
     print(line)
     os.makedirs(OUT, exist_ok=True)

@@ -41,12 +41,25 @@ class XpGemmDesc(C.Structure):
     ]
 
 
+class XpAdamTensor(C.Structure):
+    _fields_ = [("p", vp), ("m", vp), ("v", vp), ("shadow", vp), ("numel", i64), ("shadow_dtype", i32), ("reserved", i32)]
+
+
+class XpAdamGroup(C.Structure):
+    _fields_ = [("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("step_size", f32)]
+
+
+XP_OPT_CHUNK, XP_OPT_MAX_TENSORS, XP_OPT_MAX_GROUPS = 65536, 256, 16
+
 # name -> (restype, argtypes); mirrors include/xpretrain_hip.h one-to-one
 SIGNATURES = {
     "xp_abi_version": (i32, []),
     "xp_last_error": (C.c_char_p, []),
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
     "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
+    "xp_grad_sqnorm_partials": (i32, [vp, vp, i32, C.POINTER(vp), i32, vp, vp]),
+    "xp_adamw_step": (i32, [vp, vp, i32, C.POINTER(vp), C.POINTER(C.c_uint8), i32, C.POINTER(XpAdamGroup), i32, vp, i32, f32,
+                            vp, vp]),
     "xp_splitk_reduce": (i32, [vp, vp, i64, i32, i32, vp]),
     "xp_colsum_workspace_bytes": (sz, [i64, i64]),
     "xp_colsum": (i32, [vp, i64, i64, i64, i32, vp, i32, vp, sz, vp]),

@@ -23,66 +23,111 @@ from . import hip_ops as H
 
 
 # ------------------------------------------------------------------------------------------ weights
+class _Entry:
+    __slots__ = ("ver", "buf", "refs")
+
+    def __init__(self, ver, buf, refs):
+        self.ver, self.buf, self.refs = ver, buf, refs
+
+
 class WeightCache:
     """Compute-dtype copies of fp32 master weights.  An entry is refreshed when (a) the parameter's version counter
     moved (``load_state_dict`` / in-place edits), or (b) ANY optimizer stepped since the copy was made -- fused / foreach
     optimizers update parameters without bumping ``Tensor._version`` (observed with ``AdamW(fused=True)``), so a global
-    optimizer-step hook advances ``generation``.  ``invalidate()`` forces a refresh by hand."""
+    optimizer-step hook advances ``generation``.  ``invalidate()`` forces a refresh by hand.  An optimizer that rewrites
+    the copies itself (``optimization.AdamW``: the shadows are written by the update kernel) asks for their addresses
+    with ``shadow_bindings`` and keeps them valid through ``invalidate(keep=...)``."""
 
     def __init__(self):
         self._c = {}
         self.generation = 0
+        self.structure_version = 0      # bumped whenever a cached buffer is (re)allocated
         self._hooked = False
 
     def _ensure_hook(self):
         if not self._hooked:
             from torch.optim.optimizer import register_optimizer_step_post_hook
-            register_optimizer_step_post_hook(lambda opt, args, kwargs: self.invalidate())
+
+            def hook(opt, args, kwargs):
+                after = getattr(opt, "_xp_after_step", None)
+                if after is not None:
+                    after(self)
+                else:
+                    self.invalidate()
+            register_optimizer_step_post_hook(hook)
             self._hooked = True
 
-    def invalidate(self):
+    def _ver(self, ws):
+        return tuple((w._version, w.data_ptr(), self.generation) for w in ws)
+
+    def invalidate(self, keep=None):
+        """Every cached copy goes stale, except the entries in ``keep`` (a list from ``shadow_bindings``) which the
+        caller has just rewritten from the current master values."""
         self.generation += 1
+        for key, ent in keep or ():
+            if self._c.get(key) is ent:
+                ws = [r() for r in ent.refs]
+                if all(w is not None for w in ws):
+                    ent.ver = self._ver(ws)
 
     @staticmethod
     def _alive(ent, ws) -> bool:
         """ids are only unique among LIVE objects: an entry is valid only while its weak references still point at
         the very tensors being asked about (a freed model's id can be reused by a new parameter)."""
-        return ent is not None and all(r() is w for r, w in zip(ent[2], ws))
+        return ent is not None and all(r() is w for r, w in zip(ent.refs, ws))
 
     def get(self, w: torch.Tensor, dtype) -> torch.Tensor:
         if dtype == torch.float32:
             return w.detach()
-        self._ensure_hook()
-        key = (id(w), dtype)
-        ent = self._c.get(key)
-        ver = (w._version, w.data_ptr(), self.generation)
-        if not self._alive(ent, (w,)) or ent[0] != ver:
-            buf = ent[1] if ent is not None and ent[1].shape == w.shape and ent[1].device == w.device else None
-            ent = (ver, H.cast(w.detach(), dtype, out=buf), (weakref.ref(w),))
-            self._c[key] = ent
-        return ent[1]
+        return self.fused((w,), dtype, _single=True)
 
-    def fused(self, ws, dtype) -> torch.Tensor:
+    def fused(self, ws, dtype, _single=False) -> torch.Tensor:
         """Row-concatenation of several [n_i, k] weights (or 1-D biases) in `dtype`: the fused QKV operand."""
         self._ensure_hook()
         key = (tuple(id(w) for w in ws), dtype)
-        ver = tuple((w._version, w.data_ptr(), self.generation) for w in ws)
+        ver = self._ver(ws)
         ent = self._c.get(key)
-        if not self._alive(ent, ws) or ent[0] != ver:
-            rows = sum(w.shape[0] for w in ws)
-            shape = (rows,) + tuple(ws[0].shape[1:])
-            reuse = ent is not None and tuple(ent[1].shape) == shape and ent[1].device == ws[0].device
-            buf = ent[1] if reuse else torch.empty(shape, dtype=dtype, device=ws[0].device)
-            r = 0
-            for w in ws:
-                H.cast(w.detach(), dtype, out=buf[r:r + w.shape[0]])
-                r += w.shape[0]
-            ent = (ver, buf, tuple(weakref.ref(w) for w in ws))
+        if not self._alive(ent, ws) or ent.ver != ver:
+            rows = sum(w.shape[0] for w in ws) if not _single else ws[0].shape[0]
+            shape = tuple(ws[0].shape) if _single else (rows,) + tuple(ws[0].shape[1:])
+            reuse = ent is not None and tuple(ent.buf.shape) == shape and ent.buf.device == ws[0].device
+            if not reuse:
+                self.structure_version += 1
+            buf = ent.buf if reuse else torch.empty(shape, dtype=dtype, device=ws[0].device)
+            if _single:
+                H.cast(ws[0].detach(), dtype, out=buf)
+            else:
+                r = 0
+                for w in ws:
+                    H.cast(w.detach(), dtype, out=buf[r:r + w.shape[0]])
+                    r += w.shape[0]
+            ent = _Entry(ver, buf, tuple(weakref.ref(w) for w in ws))
             self._c[key] = ent
-        return ent[1]
+        return ent.buf
+
+    def shadow_bindings(self, params):
+        """For an optimizer that rewrites the cached copies in its update kernel: ``({id(p): (device address, XP dtype
+        code)}, entries)`` over the cache entries ALL of whose source tensors are in ``params`` (at most one copy per
+        parameter; any other copy simply goes stale at the step)."""
+        ids = {id(p) for p in params}
+        shadows, entries = {}, []
+        for key, ent in self._c.items():
+            ws = [r() for r in ent.refs]
+            if any(w is None or id(w) not in ids or id(w) in shadows for w in ws) or not ent.buf.is_contiguous():
+                continue
+            code = {torch.bfloat16: 0, torch.float32: 1}.get(ent.buf.dtype)
+            if code is None:
+                continue
+            off = 0
+            for w in ws:
+                shadows[id(w)] = (ent.buf.data_ptr() + off * ent.buf.element_size(), code)
+                off += w.numel()
+            entries.append((key, ent))
+        return shadows, entries
 
     def clear(self):
         self._c.clear()
+        self.structure_version += 1
 
 
 WEIGHTS = WeightCache()
