@@ -6,18 +6,21 @@
 // the bytes staged per FLOP (64 KiB per 2048 MFMA cycles) and doubles the MFMAs per LDS fragment read.
 //
 //   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 accumulators (128 registers)
-//   k-tile     64 bf16 of k = four 16 KiB HALF-TILES, consumed in the order A0, B0, B1, A1.  Half h of the M-side tile
-//              holds rows {wm*128 + h*64 + r} (r < 64) of both wave rows, half h of the N-side tile rows
-//              {wn*64 + h*32 + r} (r < 32) of all four wave columns: every wave needs 64 x 32 of its output per
-//              (A half, B half) pair, so one k-tile is four PHASES of 16 MFMAs: (A0,B0) (A0,B1) (A1,B1) (A1,B0), and
-//              only one new register sub-tile is read from LDS per phase (8+4, 4, 8, 0 ds_read_b128).
-//   ring       8 half-tile slots = 128 KiB LDS; half-tile j = 4*kt + which lives in slot j % 8.  Phase q issues the
-//              DMA (2 x buffer_load ... lds per lane) of half-tile q+6, then waits vmcnt(8): everything phase q+1 reads
-//              has landed in every wave before the barrier that separates the two phases.  The slot written by phase q
-//              was last read in phase q-2 (A0) or earlier, two barriers back even for the lagging wave group.
-//   ping-pong  each phase is  [reads, DMA issue, vmcnt] barrier [16 MFMA at raised priority] barrier ; the wm==1 waves
+//   k-tile     64 bf16 of k = four 16 KiB HALF-TILES.  Half h of the M-side tile holds rows {wm*128 + h*64 + r} (r < 64)
+//              of both wave rows, half h of the N-side tile rows {wn*64 + h*32 + r} (r < 32) of all four wave columns,
+//              so every wave needs 64 rows of an A half and 32 rows of a B half.  One k-tile is two PHASES of 32 MFMAs:
+//              A0 x (B0, B1), then A1 x (B0, B1); each phase reads 12 fragments (8 of its A half + 4 of B1, resp. of the
+//              NEXT k-tile's B0, which is kept in registers) and issues the DMA of two half-tiles.
+//   ring       8 half-tile slots = 128 KiB LDS.  Consumption order j = 4*kt + w, w = A0(kt), B1(kt), A1(kt), B0(kt+1);
+//              slot j % 8.  Phase p reads half-tiles 2p, 2p+1 and issues 2p+4, 2p+5 (one k-tile ahead), then waits
+//              vmcnt(4): everything phase p+1 reads has landed in every wave before the barrier that separates the
+//              phases.  The slots written in phase p were last read in phase p-2 -- two barriers back even for the
+//              lagging wave group, which is what the staggered schedule needs (a deeper look-ahead would not be).
+//   ping-pong  each phase is  [reads, DMA issue, vmcnt] barrier [32 MFMA at raised priority] barrier ; the wm==1 waves
 //              run one barrier behind the wm==0 waves (one extra s_barrier up front, one extra for wm==0 at the end),
 //              so on every SIMD one wave issues MFMAs while the other reads fragments and issues DMA.
+//              Measured (tools/gemm_trace256.py): 2400 cycles per k-tile = 85 % MFMA duty in steady state (16-MFMA
+//              phases with four barriers pairs per k-tile: 2700); prologue + drain 5.9k, epilogue 4.5k cycles.
 //   epilogue   wave-private LDS staging (rounds of 32 rows x 64 cols fp32), row-major read-back, shared fused epilogue.
 //
 // History of this file (all variants were correct; numbers at BASELINE cfg #2 shapes): a plain 2-stage 256x256 loop
@@ -144,28 +147,30 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   unsigned long long* tr = p.dbg;
   if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
 
-  // slot of half-tile `which` (0:A0 1:B0 2:B1 3:A1) of k-tile kt
-  auto slot = [&](int kt, int which) -> char* { return smem + (((kt & 1) << 2) + which) * HALF_BYTES; };
+  // Half-tiles in consumption order: j = 4*kt + w with w 0: A0(kt), 1: B1(kt), 2: A1(kt), 3: B0(kt+1); slot j % 8.
+  // B0 of k-tile 0 ("j = -1") uses slot 7.
+  auto slot = [&](int kt, int w) -> char* { return smem + (((kt & 1) << 2) + w) * HALF_BYTES; };
 
-  // prologue: half-tiles 0..5 in flight; 0 and 1 landed everywhere before the first phase
-  ga.issue(slot(0, 0), 0, 0); gb.issue(slot(0, 1), 0, 0); gb.issue(slot(0, 2), 1, 0); ga.issue(slot(0, 3), 1, 0);
-  ga.issue(slot(1, 0), 0, 1); gb.issue(slot(1, 1), 0, 1);
-  wait_vmcnt<8>();
+  // prologue: B0(0) and half-tiles 0..3 in flight; B0(0), A0(0), B1(0) landed everywhere before the first phase
+  gb.issue(slot(1, 3), 0, 0);
+  ga.issue(slot(0, 0), 0, 0); gb.issue(slot(0, 1), 1, 0); ga.issue(slot(0, 2), 1, 0); gb.issue(slot(0, 3), 0, 1);
+  wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();       // the wm==1 group runs one barrier behind
 
-  bf16x8 fa[2][4], fb[2][2][2];                     // fa[ks][mt] (current A half), fb[hB][ks][nt]
+  bf16x8 fa[2][4], fb[2][2][2], fbn[2][2];          // fa[ks][mt] (current A half), fb[hB][ks][nt], fbn: next k-tile's B0
 
-#define XP_PHASE_MMA(HA, HB)                                                                          \
+#define XP_PHASE_MMA(HA)                                                                              \
   do {                                                                                                \
     __builtin_amdgcn_s_barrier();                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                              \
-          acc[(HB) * 2 + nt][(HA) * 4 + mt] = mma16(fb[HB][ks][nt], fa[ks][mt], acc[(HB) * 2 + nt][(HA) * 4 + mt]); \
+    _Pragma("unroll") for (int hb = 0; hb < 2; ++hb)                                                  \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
+          _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                            \
+            acc[hb * 2 + nt][(HA) * 4 + mt] = mma16(fb[hb][ks][nt], fa[ks][mt], acc[hb * 2 + nt][(HA) * 4 + mt]); \
     __builtin_amdgcn_s_setprio(0);                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     __builtin_amdgcn_s_barrier();                                                                     \
@@ -173,37 +178,37 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 #define XP_READ_A(TILE)                                                                               \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) fa[ks][mt] = frag<AKS>(TILE, wm * 4 + mt, ks, lane)
-#define XP_READ_B(HB, TILE)                                                                           \
+#define XP_READ_B(DST, TILE)                                                                          \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
-    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) fb[HB][ks][nt] = frag<BKS>(TILE, wn * 2 + nt, ks, lane)
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) DST[ks][nt] = frag<BKS>(TILE, wn * 2 + nt, ks, lane)
 
-  // One k-tile = 4 phases.  TAIL 0: steady state, 1: k-tile nk-2, 2: k-tile nk-1 (fewer half-tiles left to issue/await).
+  XP_READ_B(fbn, slot(1, 3));                       // B0 of k-tile 0
+
+  // One k-tile = 2 phases of 32 MFMAs: A0 x (B0, B1), then A1 x (B0, B1); 12 fragment reads and 2 half-tile DMAs each.
+  // TAIL 0: steady state, 1: k-tile nk-2, 2: k-tile nk-1 (fewer half-tiles left to issue / await).
   auto ktile = [&](int t, auto tail_c) {
     constexpr int TAIL = decltype(tail_c)::value;
-    // ---- phase 0: (A0, B0) ----
-    XP_READ_B(0, slot(t, 1));
+    // ---- phase 0: A0 x (B0, B1); issues A0, B1 of k-tile t+1; afterwards A1(t) and B0(t+1) have landed ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) fb[0][ks][nt] = fbn[ks][nt];
+    XP_READ_B(fb[1], slot(t, 1));
     __builtin_amdgcn_sched_barrier(0);
     XP_READ_A(slot(t, 0));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TAIL <= 1) gb.issue(slot(t + 1, 2), 1, t + 1);
-    wait_vmcnt<(TAIL <= 1 ? 8 : 2)>();
-    XP_PHASE_MMA(0, 0);
-    // ---- phase 1: (A0, B1) ----
-    XP_READ_B(1, slot(t, 2));
+    if constexpr (TAIL <= 1) { ga.issue(slot(t + 1, 0), 0, t + 1); gb.issue(slot(t + 1, 1), 1, t + 1); }
+    wait_vmcnt<(TAIL <= 1 ? 4 : 0)>();
+    XP_PHASE_MMA(0);
+    // ---- phase 1: A1 x (B0, B1); issues A1(t+1), B0(t+2); afterwards A0, B1 of k-tile t+1 have landed ----
+    if constexpr (TAIL <= 1) { XP_READ_B(fbn, slot(t, 3)); }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TAIL <= 1) ga.issue(slot(t + 1, 3), 1, t + 1);
-    wait_vmcnt<(TAIL <= 1 ? 8 : 0)>();
-    XP_PHASE_MMA(0, 1);
-    // ---- phase 2: (A1, B1) ----
-    XP_READ_A(slot(t, 3));
+    XP_READ_A(slot(t, 2));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TAIL == 0) ga.issue(slot(t, 0), 0, t + 2);
-    wait_vmcnt<(TAIL == 0 ? 8 : (TAIL == 1 ? 6 : 0))>();
-    XP_PHASE_MMA(1, 1);
-    // ---- phase 3: (A1, B0) ----
-    if constexpr (TAIL == 0) gb.issue(slot(t, 1), 0, t + 2);
-    wait_vmcnt<(TAIL == 0 ? 8 : (TAIL == 1 ? 4 : 0))>();
-    XP_PHASE_MMA(1, 0);
+    if constexpr (TAIL <= 1) ga.issue(slot(t + 1, 2), 1, t + 1);
+    if constexpr (TAIL == 0) gb.issue(slot(t + 1, 3), 0, t + 2);
+    wait_vmcnt<(TAIL == 0 ? 4 : (TAIL == 1 ? 2 : 0))>();
+    XP_PHASE_MMA(1);
   };
   for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
   ktile(nk - 2, std::integral_constant<int, 1>{});
