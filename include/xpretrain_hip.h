@@ -206,6 +206,15 @@ int xp_nce_loss(const float* vis, const float* txt, const float* log_scale, floa
                 float* d_vis, float* d_txt, float* d_log_scale, int64_t n, int64_t d,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* NCELearnableTempLoss_vsc_fc.forward (optimization/loss.py:296-324, the pre-training default,
+ * pretrain_vip_base_16.json:75) on gathered unit-norm features vis/txt/img/cap [n,d] (fp32): six cross-entropies
+ * over video-subtitle, video-caption (off-diagonal negatives of both re-packed behind either positive, :307-314)
+ * and frame-caption logits.  One call computes the loss and d loss / d{vis, txt, img, cap, log_scale}. */
+size_t xp_vsc_fc_loss_workspace_bytes(int64_t n, int64_t d);
+int xp_vsc_fc_loss(const float* vis, const float* txt, const float* img, const float* cap, const float* log_scale,
+                   float* loss, float* d_vis, float* d_txt, float* d_img, float* d_cap, float* d_log_scale,
+                   int64_t n, int64_t d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* -------------------------------------------------------------------------------------- Diagnostics
  * Hardware-layout probes used by tests/test_probe_gpu.py to pin the MFMA / LDS-transpose lane maps
  * this library relies on (out buffers are small device arrays; see csrc/probe.hip). */

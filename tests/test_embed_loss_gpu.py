@@ -121,3 +121,38 @@ def test_nce_loss_large_n_fp64():
     assert report("nce200 dV", dv, vd.grad, 1e-4) <= 1e-4
     assert report("nce200 dT", dt, td.grad, 1e-4) <= 1e-4
     assert abs(dls.item() - lsd.grad.item()) < 1e-3
+
+
+def test_vsc_fc_loss_against_reference_fixtures(golden):
+    """fp32 kernel vs outputs of the reference's NCELearnableTempLoss_vsc_fc (tests/golden/loss.pt), through the module
+    surface (autograd): loss, d{vis, txt, img, cap}, d log_scale."""
+    from xpretrain_amd.optimization import build_loss_func
+    fn = build_loss_func({"loss_name": "NCELearnableTempLoss_vsc_fc"})
+    for c in golden("loss.pt"):
+        feats = [f.cuda().requires_grad_() for f in c["feats"]]
+        ls = torch.tensor(c["log_scale"], device="cuda", requires_grad=True)
+        loss = fn(feats[0], feats[1], feats[2], feats[3], ls)
+        grads = torch.autograd.grad(loss * 2.0, feats + [ls])            # incoming scalar 2.0 exercises backward scaling
+        tag = f"vsc_fc n={c['n']} ls={c['log_scale']:.2f}"
+        assert abs(loss.item() - c["vsc_fc"].item()) <= 1e-3 * max(1.0, abs(c["vsc_fc"].item())), tag
+        for name, g, r in zip(("dV", "dT", "dI", "dC"), grads[:4], c["vsc_fc_grads"][:4]):
+            assert report(f"{tag} {name}", g / 2.0, r, 1e-3) <= 1e-3
+        r = c["vsc_fc_grads"][4].item()
+        assert abs(grads[4].item() / 2.0 - r) <= 1e-3 * max(1.0, abs(r)), tag
+
+
+def test_vsc_fc_loss_large_n_fp64():
+    """n=200 (> one wave, > one sgemm tile) against the fp64 oracle."""
+    from oracle import clipvip_oracle as O
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(21)
+    n, d = 200, 96
+    feats = [torch.nn.functional.normalize(torch.randn(n, d, dtype=torch.float64), dim=-1).requires_grad_() for _ in range(4)]
+    ls = torch.tensor(3.7, dtype=torch.float64, requires_grad=True)
+    ref = O.nce_vsc_fc_loss(*feats, ls)
+    rg = torch.autograd.grad(ref, feats + [ls])
+    out = H.vsc_fc_loss(*[f.detach().float().cuda() for f in feats], ls.detach().float().cuda())
+    assert abs(out[0].item() - ref.item()) <= 1e-4 * abs(ref.item())
+    for name, g, r in zip(("dV", "dT", "dI", "dC"), out[1:5], rg[:4]):
+        assert report(f"vsc_fc200 {name}", g, r, 1e-4) <= 1e-4
+    assert abs(out[5].item() - rg[4].item()) <= 1e-4 * max(1.0, abs(rg[4].item()))

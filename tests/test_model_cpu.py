@@ -64,8 +64,9 @@ def test_non_vip_and_unknown_loss_fail_loudly():
     with pytest.raises(NotImplementedError):
         VidCLIP(_Args(O.hf_config_dict(128, 2, 1, 256, 16, 32, 128, 2, 1, 256, 120, 16, 64), typ="ST"))
     assert build_loss_func({"loss_name": "NCELearnableTempLoss"}) is not None
+    assert build_loss_func({"loss_name": "NCELearnableTempLoss_vsc_fc"}) is not None
     with pytest.raises(NotImplementedError):
-        build_loss_func({"loss_name": "NCELearnableTempLoss_vsc_fc"})
+        build_loss_func({"loss_name": "NCEHardNegLoss"})
 
 
 def test_no_cpu_fallback():

@@ -142,3 +142,43 @@ def test_weight_cache_follows_optimizer_steps():
     sd = {k: v.detach().cpu() for k, v in O.strip_prefix(model.state_dict()).items()}
     ref, _ = O.clip_features(video.cpu(), ids.cpu(), mask.cpu(), sd, O.OracleCfg.from_hf_dict(cfgd, temporal_size=2))
     assert (f1.cpu() - ref).abs().max().item() < 2e-2
+
+
+def test_pretrain_step_dual_pass_vsc_fc_against_oracle():
+    """the pre-training step of run_pretrain -- video+subtitle pass, middle-frame image + caption pass at
+    T=1 (VidCLIP.py:70-79), NCELearnableTempLoss_vsc_fc (loss.py:288-324) -- forward, loss and EVERY parameter gradient
+    (both passes accumulate into the shared weights) against the fp32 oracle."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import build_loss_func
+    torch.manual_seed(11)
+    cfgd = O.hf_config_dict(128, 2, 2, 256, 16, 32, 128, 2, 2, 256, 120, 16, 64)
+    model = VidCLIP(_Args(cfgd, 4))
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.1)
+    B = 4
+    video, ids, mask = O.synthetic_inputs(B, 4, 32, 8, vocab=120)
+    _, cap_ids, cap_mask = O.synthetic_inputs(B, 1, 32, 8, vocab=120, seed=99)
+    image = video[:, 1:2].contiguous()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
+    cfg = O.OracleCfg.from_hf_dict(cfgd, temporal_size=4)
+    rv, rt = O.clip_features(video, ids, mask, sd, cfg)
+    ri, rc = O.clip_features(image, cap_ids, cap_mask, sd, cfg)
+    ref_loss = O.nce_vsc_fc_loss(rv, rt, ri, rc, sd["logit_scale"])
+    ref_loss.backward()
+    model.cuda().train()
+    out = model(video.cuda(), ids.cuda(), mask.cuda(), image=image.cuda(), caption_ids=cap_ids[:, None].cuda(),
+                caption_masks=cap_mask[:, None].cuda())
+    loss = build_loss_func({"loss_name": "NCELearnableTempLoss_vsc_fc"})(
+        out["vis_features"], out["text_features"], out["img_features"], out["cap_features"], model.clipmodel.logit_scale)
+    loss.backward()
+    for k, r in (("vis_features", rv), ("text_features", rt), ("img_features", ri), ("cap_features", rc)):
+        assert (out[k].detach().cpu() - r).abs().max().item() < 2e-2, k
+    print(f"pretrain step: loss {loss.item():.5f} oracle {ref_loss.item():.5f}")
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * max(1.0, abs(ref_loss.item()))
+    worst = 0.0
+    for name, p in model.named_parameters():
+        ref = sd[name[len("clipmodel."):]].grad
+        assert p.grad is not None and ref is not None, name
+        if ref.abs().max() > 1e-5:
+            worst = max(worst, report(f"pretrain-step grad {name}", p.grad, ref, 8e-2))
+    assert worst <= 8e-2

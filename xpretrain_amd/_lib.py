@@ -84,6 +84,8 @@ SIGNATURES = {
     "xp_cast_back": (i32, [vp, vp, i64, i32, i32, vp]),
     "xp_nce_loss_workspace_bytes": (sz, [i64, i64]),
     "xp_nce_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, sz, vp]),
+    "xp_vsc_fc_loss_workspace_bytes": (sz, [i64, i64]),
+    "xp_vsc_fc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, sz, vp]),
     "xp_debug_set_gemm_trace": (i32, [vp]),
     "xp_debug_gemm_occupancy": (i32, [i32]),
     "xp_probe_mfma_bf16": (i32, [vp, vp, vp, vp]),

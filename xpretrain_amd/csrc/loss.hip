@@ -13,7 +13,7 @@ namespace {
 __global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restrict__ X, int64_t sxi, int64_t sxk,
                                                             const float* __restrict__ Y, int64_t syk, int64_t syj,
                                                             float* __restrict__ C, int64_t ldc, int I, int J, int K,
-                                                            const float* __restrict__ log_scale) {
+                                                            const float* __restrict__ log_scale, int accumulate = 0) {
   __shared__ float xs[32][33], ys[32][33];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
-      if (i < I && j < J) C[(int64_t)i * ldc + j] = alpha * acc[a][b];
+      if (i < I && j < J) {
+        float* c = C + (int64_t)i * ldc + j;
+        *c = accumulate ? *c + alpha * acc[a][b] : alpha * acc[a][b];
+      }
     }
 }
 
@@ -86,7 +89,116 @@ __global__ void finish_kernel(const float* __restrict__ part, float* loss, float
   if (lane == 0) { *loss = a; *d_ls = b; }
 }
 
+// ---- NCELearnableTempLoss_vsc_fc (optimization/loss.py:288-324) ---------------------------------------------------------
+//   S1 = s V T^T (video-subtitle), S2 = s V C^T (video-caption), S3 = s I C^T (frame-caption), s = exp(ls)
+//   loss = mean_i [ (c1_i - S1_ii) + (c2_i - S2_ii) + (ra_i - S1_ii) + (rb_i - S2_ii) + (c3_i - S3_ii) + (r3_i - S3_ii) ]
+//   c*_j = lse over column j;  r3_i = lse over row i of S3;
+//   ra_i = lse(S1[i,:] U S2[i,j!=i])   (loss.py:311 [pos, neg, neg_2] with pos = S1_ii)
+//   rb_i = lse(S1[i,j!=i] U S2[i,:])   (loss.py:312 with pos = S2_ii)
+// blocks 0..n-1: row i -> ra, rb, r3 ; blocks n..2n-1: column j -> c1, c2, c3   (one wave each)
+__global__ void vsc_lse_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ S3,
+                               float* __restrict__ st, int n) {
+  const int lane = threadIdx.x;
+  float* ra = st; float* rb = st + n; float* r3 = st + 2 * n; float* c1 = st + 3 * n; float* c2 = st + 4 * n; float* c3 = st + 5 * n;
+  if ((int)blockIdx.x < n) {
+    const int i = blockIdx.x;
+    const float* a = S1 + (int64_t)i * n; const float* b = S2 + (int64_t)i * n; const float* c = S3 + (int64_t)i * n;
+    float mab = -INFINITY, m3 = -INFINITY;
+    for (int j = lane; j < n; j += 64) { mab = fmaxf(mab, fmaxf(a[j], b[j])); m3 = fmaxf(m3, c[j]); }
+    mab = wave_max(mab); m3 = wave_max(m3);
+    float sa = 0.f, sb = 0.f, s3 = 0.f;
+    for (int j = lane; j < n; j += 64) {
+      const float ea = expf(a[j] - mab), eb = expf(b[j] - mab);
+      sa += ea + (j == i ? 0.f : eb);
+      sb += (j == i ? 0.f : ea) + eb;
+      s3 += expf(c[j] - m3);
+    }
+    sa = wave_sum(sa); sb = wave_sum(sb); s3 = wave_sum(s3);
+    if (lane == 0) { ra[i] = mab + logf(sa); rb[i] = mab + logf(sb); r3[i] = m3 + logf(s3); }
+  } else {
+    const int j = blockIdx.x - n;
+    float m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+      m1 = fmaxf(m1, S1[(int64_t)i * n + j]); m2 = fmaxf(m2, S2[(int64_t)i * n + j]); m3 = fmaxf(m3, S3[(int64_t)i * n + j]);
+    }
+    m1 = wave_max(m1); m2 = wave_max(m2); m3 = wave_max(m3);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      s1 += expf(S1[(int64_t)i * n + j] - m1); s2 += expf(S2[(int64_t)i * n + j] - m2); s3 += expf(S3[(int64_t)i * n + j] - m3);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if (lane == 0) { c1[j] = m1 + logf(s1); c2[j] = m2 + logf(s2); c3[j] = m3 + logf(s3); }
+  }
+}
+
+// block i: rows i of G1, G2, G3 (d loss / d S*) ; part[i] = (loss_i, dls_i)
+__global__ void vsc_grad_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ S3,
+                                const float* __restrict__ st, float* __restrict__ G1, float* __restrict__ G2,
+                                float* __restrict__ G3, float* __restrict__ part, int n) {
+  const int lane = threadIdx.x, i = blockIdx.x;
+  const float* ra = st; const float* rb = st + n; const float* r3 = st + 2 * n;
+  const float* c1 = st + 3 * n; const float* c2 = st + 4 * n; const float* c3 = st + 5 * n;
+  const float inv = 1.0f / (float)n, rai = ra[i], rbi = rb[i], r3i = r3[i];
+  float dls = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const int64_t o = (int64_t)i * n + j;
+    const float a = S1[o], b = S2[o], c = S3[o];
+    const bool dg = i == j;
+    const float g1 = (expf(a - c1[j]) + expf(a - rai) + (dg ? -2.0f : expf(a - rbi))) * inv;
+    const float g2 = (expf(b - c2[j]) + expf(b - rbi) + (dg ? -2.0f : expf(b - rai))) * inv;
+    const float g3 = (expf(c - c3[j]) + expf(c - r3i) - (dg ? 2.0f : 0.0f)) * inv;
+    G1[o] = g1; G2[o] = g2; G3[o] = g3;
+    dls += g1 * a + g2 * b + g3 * c;
+  }
+  dls = wave_sum(dls);
+  if (lane == 0) {
+    const int64_t d = (int64_t)i * n + i;
+    part[2 * i] = ((c1[i] - S1[d]) + (c2[i] - S2[d]) + (rai - S1[d]) + (rbi - S2[d]) + (c3[i] - S3[d]) + (r3i - S3[d])) * inv;
+    part[2 * i + 1] = dls;
+  }
+}
+
 }  // namespace
+
+extern "C" size_t xp_vsc_fc_loss_workspace_bytes(int64_t n, int64_t d) {
+  (void)d;
+  return (size_t)(6 * n * n + 8 * n) * sizeof(float);   // S1..S3, G1..G3, 6 lse vectors, part[2n]
+}
+
+extern "C" int xp_vsc_fc_loss(const float* vis, const float* txt, const float* img, const float* cap, const float* log_scale,
+                              float* loss, float* d_vis, float* d_txt, float* d_img, float* d_cap, float* d_log_scale,
+                              int64_t n, int64_t d, void* workspace, size_t workspace_bytes, void* stream) {
+  XP_REQUIRE(vis && txt && img && cap && log_scale && loss && d_vis && d_txt && d_img && d_cap && d_log_scale,
+             "xp_vsc_fc_loss: null pointer");
+  XP_REQUIRE(n > 0 && d > 0 && n <= 16384, "xp_vsc_fc_loss: bad sizes n=%lld d=%lld", (long long)n, (long long)d);
+  XP_REQUIRE(workspace && workspace_bytes >= xp_vsc_fc_loss_workspace_bytes(n, d), "xp_vsc_fc_loss: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* S1 = (float*)workspace; float* S2 = S1 + n * n; float* S3 = S2 + n * n;
+  float* G1 = S3 + n * n; float* G2 = G1 + n * n; float* G3 = G2 + n * n;
+  float* stats = G3 + n * n;
+  float* part = stats + 6 * n;
+  const int N = (int)n, D = (int)d;
+  dim3 gnn((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32)), gnd((unsigned)cdiv(d, 32), (unsigned)cdiv(n, 32));
+  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, txt, 1, d, S1, n, N, N, D, log_scale);
+  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, cap, 1, d, S2, n, N, N, D, log_scale);
+  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(img, d, 1, cap, 1, d, S3, n, N, N, D, log_scale);
+  XP_CHECK_LAUNCH("xp_vsc_fc_loss(logits)");
+  vsc_lse_kernel<<<(unsigned)(2 * n), 64, 0, st>>>(S1, S2, S3, stats, N);
+  XP_CHECK_LAUNCH("xp_vsc_fc_loss(lse)");
+  vsc_grad_kernel<<<(unsigned)n, 64, 0, st>>>(S1, S2, S3, stats, G1, G2, G3, part, N);
+  XP_CHECK_LAUNCH("xp_vsc_fc_loss(grad)");
+  finish_kernel<<<1, 64, 0, st>>>(part, loss, d_log_scale, N);
+  XP_CHECK_LAUNCH("xp_vsc_fc_loss(finish)");
+  // dV = s (G1 T + G2 C) ; dT = s G1^T V ; dC = s (G2^T V + G3^T I) ; dI = s G3 C
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G1, n, 1, txt, d, 1, d_vis, d, N, D, N, log_scale, 0);
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G2, n, 1, cap, d, 1, d_vis, d, N, D, N, log_scale, 1);
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G1, 1, n, vis, d, 1, d_txt, d, N, D, N, log_scale, 0);
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G2, 1, n, vis, d, 1, d_cap, d, N, D, N, log_scale, 0);
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G3, 1, n, img, d, 1, d_cap, d, N, D, N, log_scale, 1);
+  sgemm_strided_kernel<<<gnd, 256, 0, st>>>(G3, n, 1, cap, d, 1, d_img, d, N, D, N, log_scale, 0);
+  XP_CHECK_LAUNCH("xp_vsc_fc_loss(grads)");
+  return XP_OK;
+}
 
 extern "C" size_t xp_nce_loss_workspace_bytes(int64_t n, int64_t d) {
   (void)d;

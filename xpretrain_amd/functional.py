@@ -375,6 +375,21 @@ class NCELossFn(torch.autograd.Function):
         return dv * g, dt * g, dls * g
 
 
+class VscFcLossFn(torch.autograd.Function):
+    """NCELearnableTempLoss_vsc_fc.forward (optimization/loss.py:296-324); loss and gradients in one kernel pass."""
+
+    @staticmethod
+    def forward(ctx, vis, txt, img, cap, log_scale):
+        loss, *grads = H.vsc_fc_loss(vis.contiguous().float(), txt.contiguous().float(), img.contiguous().float(),
+                                     cap.contiguous().float(), log_scale.detach().float().reshape(()))
+        ctx.save_for_backward(*grads)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(t * g for t in ctx.saved_tensors)
+
+
 def encoder_layer(x, layer, B, S, heads, size, pad_mask):
     """Apply ``EncoderLayerFn`` with the parameters of a ``CLIPEncoderLayer`` module."""
     a, m = layer.self_attn, layer.mlp

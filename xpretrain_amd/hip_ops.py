@@ -284,6 +284,26 @@ def nce_loss(vis: torch.Tensor, txt: torch.Tensor, log_scale: torch.Tensor):
     return loss, dv, dt, dls
 
 
+def vsc_fc_loss(vis, txt, img, cap, log_scale):
+    """Returns (loss, d_vis, d_txt, d_img, d_cap, d_log_scale) -- fp32 device tensors."""
+    for t, name in ((vis, "vis"), (txt, "txt"), (img, "img"), (cap, "cap"), (log_scale, "log_scale")):
+        _chk(t, name, torch.float32)
+    n, d = vis.shape
+    if not (txt.shape == img.shape == cap.shape == vis.shape):
+        raise ValueError(f"vsc_fc_loss: feature shapes differ: {tuple(vis.shape)}, {tuple(txt.shape)}, "
+                         f"{tuple(img.shape)}, {tuple(cap.shape)}")          # loss.py:297 asserts text/cap only
+    dev = vis.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dls = torch.empty((), dtype=torch.float32, device=dev)
+    grads = [torch.empty_like(vis) for _ in range(4)]
+    nb = L.lib().xp_vsc_fc_loss_workspace_bytes(n, d)
+    ws = workspace(nb, dev, "loss")
+    L.check(L.lib().xp_vsc_fc_loss(_p(vis), _p(txt), _p(img), _p(cap), _p(log_scale), _p(loss), _p(grads[0]),
+                                   _p(grads[1]), _p(grads[2]), _p(grads[3]), _p(dls), n, d, _p(ws), ws.numel(),
+                                   _stream()), "xp_vsc_fc_loss")
+    return (loss, *grads, dls)
+
+
 # --------------------------------------------------------------------------------------- attention
 def _attn_ws(mode, B, H, M, N, Lp, device):
     nb = L.lib().xp_attn_workspace_bytes(mode, B, H, M, N, Lp)

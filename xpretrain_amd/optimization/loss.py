@@ -21,12 +21,23 @@ class NCELearnableTempLoss(nn.Module):
         return XF.NCELossFn.apply(vis_feat, text_feat, temp)
 
 
-_LOSSES = {"NCELearnableTempLoss": NCELearnableTempLoss}
+class NCELearnableTempLoss_vsc_fc(nn.Module):
+    """Pre-training default (loss.py:288-324, pretrain_vip_base_16.json:75): video-(subtitle, caption) and
+    frame-caption contrast, six cross-entropy terms; same call signature as the reference."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+
+    def forward(self, vis_feat, text_feat, img_feat, cap_feat, temp):
+        assert text_feat.shape[0] == cap_feat.shape[0]                       # loss.py:297
+        return XF.VscFcLossFn.apply(vis_feat, text_feat, img_feat, cap_feat, temp)
+
+
+_LOSSES = {"NCELearnableTempLoss": NCELearnableTempLoss, "NCELearnableTempLoss_vsc_fc": NCELearnableTempLoss_vsc_fc}
 
 
 def build_loss_func(cfg):
     name = cfg["loss_name"] if isinstance(cfg, dict) else cfg.loss_name
     if name not in _LOSSES:
-        raise NotImplementedError(f"loss {name!r} is not built yet; available on the HIP path: {sorted(_LOSSES)} "
-                                  "(NCELearnableTempLoss_vsc_fc is the next row of SURVEY.md §8f)")
+        raise NotImplementedError(f"loss {name!r} is not on the CLIP-ViP path; available on the HIP path: {sorted(_LOSSES)}")
     return _LOSSES[name](cfg)
