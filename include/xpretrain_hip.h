@@ -88,6 +88,25 @@ size_t xp_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* out,
               int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Deferred form: first level only.  partials[r*cols + n] = sum over the r-th chunk of rows of X[.][n];
+ * xp_colsum_partial_rows(rows) chunks.  Finish with xp_reduce_rows_batch. */
+int64_t xp_colsum_partial_rows(int64_t rows);
+int xp_colsum_partials(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* partials,
+                       size_t partials_bytes, void* stream);
+
+/* Batched deterministic column sums of up to XP_REDUCE_MAX_SEGS fp32 partial-row arrays in TWO launches:
+ * out[c] (+)= sum_r in[r*stride + c], r < nrows, c < width.  Used to finish all bias and LayerNorm-parameter
+ * gradients of one CLIPEncoderLayer backward (modeling/CLIP_ViP.py:444-460) at once.  segs_host is a HOST array. */
+#define XP_REDUCE_MAX_SEGS 16
+typedef struct {
+  const float* in; float* out;
+  int64_t stride;                        /* row pitch of `in`, elements                                  */
+  int32_t nrows, width;
+  int32_t accumulate, reserved;
+} XpReduceSeg;
+size_t xp_reduce_rows_batch_workspace_bytes(const XpReduceSeg* segs_host, int32_t n);
+int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
+
 /* --------------------------------------------------------------------------------------- LayerNorm
  * nn.LayerNorm(eps=1e-5) of modeling/CLIP_ViP.py:404-406,855-857,720 (pre_layrnorm, layer_norm1/2,
  * post_layernorm, final_layer_norm).  Statistics in fp32; mean/rstd saved for the backward.
@@ -95,6 +114,10 @@ int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dt
 int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                      float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, void* stream);
 size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+/* dgamma == dbeta == NULL defers the parameter-gradient reduction: the workspace then holds
+ * xp_layernorm_bwd_partial_rows(rows) partial rows of [dgamma(cols) | dbeta(cols)] (pitch 2*cols) for
+ * xp_reduce_rows_batch. */
+int64_t xp_layernorm_bwd_partial_rows(int64_t rows);
 /* dx = (dres ? dres : 0) + LN'(dy);  dgamma/dbeta (+)= column sums.  dres may alias dx. */
 int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
                      const float* mean, const float* rstd, const void* dres, int64_t lddres,

@@ -45,3 +45,39 @@ def test_layernorm_strided_rows():
     y, _, _ = H.layernorm_fwd(x, g, b, B, D, ldx=S * D)
     ref = torch.nn.functional.layer_norm(x[:, 0].double(), (D,))
     assert report("ln_strided", y, ref, 6e-3) <= 6e-3
+
+
+def test_reduce_rows_batch_and_deferred_producers():
+    """xp_reduce_rows_batch: many segments, direct (<= 64 rows) and two-level, pitch > width, accumulate; and the
+    deferred forms of colsum / layernorm_bwd give the immediate forms' results (bit-identical reduction trees are
+    not required -- fp32 roundoff tolerance)."""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(4)
+    d = H.DeferredReduce(torch.device("cuda"))
+    cases, outs, refs = [(1, 64, 64), (64, 200, 256), (65, 768, 768), (589, 3072, 3072), (1024, 768, 1536), (300, 4, 8)], [], []
+    for nrows, width, stride in cases:
+        part = torch.randn(nrows, stride, device="cuda")
+        out = torch.full((width,), 3.0, device="cuda")
+        acc = nrows % 2 == 0
+        d.add(part, 0, out, nrows, width, stride, accumulate=acc)
+        outs.append(out)
+        refs.append(part[:, :width].double().sum(0) + (3.0 if acc else 0.0))
+    d.flush()
+    for (nrows, width, stride), o, r in zip(cases, outs, refs):
+        assert report(f"reduce_batch {nrows}x{width}/{stride}", o, r, 2e-6) <= 2e-6
+
+    for dtype in (torch.bfloat16, torch.float32):
+        rows, cols = 2356, 768
+        X = torch.randn(rows, cols, device="cuda").to(dtype)
+        dy, x = torch.randn(rows, cols, device="cuda").to(dtype), torch.randn(rows, cols, device="cuda").to(dtype)
+        gamma = torch.randn(cols, device="cuda")
+        mean, rstd = x.float().mean(1), 1.0 / x.float().var(1, unbiased=False).add(1e-5).sqrt()
+        d = H.DeferredReduce(X.device)
+        cs = H.colsum_deferred(X, rows, cols, d)
+        dx1, dg1, db1 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, defer=d)
+        d.flush()
+        dx0, dg0, db0 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols)
+        assert report(f"colsum deferred {dtype}", cs, H.colsum(X, rows, cols), 2e-6) <= 2e-6
+        assert torch.equal(dx0, dx1)
+        assert report(f"ln dgamma deferred {dtype}", dg1, dg0, 2e-6) <= 2e-6
+        assert report(f"ln dbeta deferred {dtype}", db1, db0, 2e-6) <= 2e-6

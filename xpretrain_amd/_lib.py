@@ -41,6 +41,14 @@ class XpGemmDesc(C.Structure):
     ]
 
 
+class XpReduceSeg(C.Structure):
+    _fields_ = [("in_", vp), ("out", vp), ("stride", i64), ("nrows", i32), ("width", i32), ("accumulate", i32),
+                ("reserved", i32)]
+
+
+XP_REDUCE_MAX_SEGS = 16
+
+
 class XpAdamTensor(C.Structure):
     _fields_ = [("p", vp), ("m", vp), ("v", vp), ("shadow", vp), ("numel", i64), ("shadow_dtype", i32), ("reserved", i32)]
 
@@ -57,6 +65,11 @@ SIGNATURES = {
     "xp_last_error": (C.c_char_p, []),
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
     "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
+    "xp_colsum_partial_rows": (i64, [i64]),
+    "xp_colsum_partials": (i32, [vp, i64, i64, i64, i32, vp, sz, vp]),
+    "xp_reduce_rows_batch_workspace_bytes": (sz, [C.POINTER(XpReduceSeg), i32]),
+    "xp_reduce_rows_batch": (i32, [C.POINTER(XpReduceSeg), i32, vp, sz, vp]),
+    "xp_layernorm_bwd_partial_rows": (i64, [i64]),
     "xp_grad_sqnorm_partials": (i32, [vp, vp, i32, C.POINTER(vp), i32, vp, vp]),
     "xp_adamw_step": (i32, [vp, vp, i32, C.POINTER(vp), C.POINTER(C.c_uint8), i32, C.POINTER(XpAdamGroup), i32, vp, i32, f32,
                             vp, vp]),

@@ -459,6 +459,62 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
   }
 }
 
+// ---- batched two-level row reduction (bias / LayerNorm-parameter gradients of one encoder layer in two launches) ----
+struct BatchArgs {
+  XpReduceSeg seg[XP_REDUCE_MAX_SEGS];
+  float* part2[XP_REDUCE_MAX_SEGS];        // level-1 output [<=32][width] per segment
+  int cb0[XP_REDUCE_MAX_SEGS + 1];         // prefix sum of 64-column blocks
+  int n;
+};
+constexpr int RB_DIRECT = 64;              // segments with <= this many rows skip level 1
+
+__device__ __forceinline__ int batch_find(const BatchArgs& a, int bx) {
+  int s = 0;
+  while (s + 1 < a.n && bx >= a.cb0[s + 1]) ++s;
+  return s;
+}
+
+// sum rows [r0, r1) of `in` (pitch `stride`) for column c; 4 waves take every 4th row, LDS combine (fixed order)
+__device__ __forceinline__ float batch_colsum(const float* __restrict__ in, int64_t stride, int r0, int r1, int c, bool ok,
+                                              float (*red)[64]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (ok) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) { s0 += in[(int64_t)r * stride + c]; s1 += in[(int64_t)(r + 4) * stride + c]; }
+    if (r < r1) s0 += in[(int64_t)r * stride + c];
+  }
+  red[w][lane] = s0 + s1;
+  __syncthreads();
+  return red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ __launch_bounds__(256) void reduce_batch_l1_kernel(BatchArgs a) {
+  __shared__ float red[4][64];
+  const int s = batch_find(a, blockIdx.x);
+  const XpReduceSeg sg = a.seg[s];
+  if (sg.nrows <= RB_DIRECT) return;
+  const int nsum = (sg.nrows + 31) / 32;
+  const int r0 = blockIdx.y * nsum;
+  if (r0 >= sg.nrows) return;
+  const int r1 = r0 + nsum < sg.nrows ? r0 + nsum : sg.nrows;
+  const int c = (blockIdx.x - a.cb0[s]) * 64 + (threadIdx.x & 63);
+  const float t = batch_colsum(sg.in, sg.stride, r0, r1, c, c < sg.width, red);
+  if (threadIdx.x < 64 && c < sg.width) a.part2[s][(int64_t)blockIdx.y * sg.width + c] = t;
+}
+
+__global__ __launch_bounds__(256) void reduce_batch_l2_kernel(BatchArgs a) {
+  __shared__ float red[4][64];
+  const int s = batch_find(a, blockIdx.x);
+  const XpReduceSeg sg = a.seg[s];
+  const bool direct = sg.nrows <= RB_DIRECT;
+  const int nsum = (sg.nrows + 31) / 32;
+  const int n2 = direct ? sg.nrows : (sg.nrows + nsum - 1) / nsum;
+  const int c = (blockIdx.x - a.cb0[s]) * 64 + (threadIdx.x & 63);
+  const float t = batch_colsum(direct ? sg.in : a.part2[s], direct ? sg.stride : (int64_t)sg.width, 0, n2, c, c < sg.width, red);
+  if (threadIdx.x < 64 && c < sg.width) sg.out[c] = sg.accumulate ? sg.out[c] + t : t;
+}
+
 }  // namespace
 
 // occupancy query for the default bf16 NT direct-to-LDS kernel: resident workgroups per CU at `lds_bytes` dynamic LDS
@@ -568,6 +624,56 @@ extern "C" int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32
   int blocks = (int)(cdiv(n4, 256) < 8192 ? cdiv(n4, 256) : 8192);
   splitk_reduce_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(slabs, out, n4, splits, accumulate);
   XP_CHECK_LAUNCH("xp_splitk_reduce");
+  return XP_OK;
+}
+
+extern "C" int64_t xp_colsum_partial_rows(int64_t rows) { return cdiv(rows, CS_ROWS); }
+
+extern "C" int xp_colsum_partials(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* partials,
+                                  size_t partials_bytes, void* stream) {
+  XP_REQUIRE(X && partials && rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0, "xp_colsum_partials: bad arguments");
+  const int chunks = (int)cdiv(rows, CS_ROWS);
+  XP_REQUIRE(partials_bytes >= (size_t)chunks * cols * sizeof(float), "xp_colsum_partials: partials buffer too small");
+  dim3 grid((unsigned)cdiv(cols, 256), chunks);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, rows, cols, ldx, partials);
+  else if (dtype == XP_F32) colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, rows, cols, ldx, partials);
+  else XP_REQUIRE(false, "xp_colsum_partials: bad dtype %d", dtype);
+  XP_CHECK_LAUNCH("xp_colsum_partials");
+  return XP_OK;
+}
+
+extern "C" size_t xp_reduce_rows_batch_workspace_bytes(const XpReduceSeg* segs_host, int32_t n) {
+  size_t b = 0;
+  for (int i = 0; segs_host && i < n; ++i) b += (size_t)32 * (size_t)(segs_host[i].width > 0 ? segs_host[i].width : 0) * sizeof(float);
+  return b + 16;
+}
+
+extern "C" int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  XP_REQUIRE(segs_host && n > 0 && n <= XP_REDUCE_MAX_SEGS, "xp_reduce_rows_batch: n=%d not in 1..%d", n, XP_REDUCE_MAX_SEGS);
+  XP_REQUIRE(workspace && workspace_bytes >= xp_reduce_rows_batch_workspace_bytes(segs_host, n), "xp_reduce_rows_batch: workspace too small");
+  BatchArgs a;
+  a.n = n;
+  float* ws = (float*)workspace;
+  int cb = 0;
+  bool any_l1 = false;
+  for (int i = 0; i < n; ++i) {
+    const XpReduceSeg& sg = segs_host[i];
+    XP_REQUIRE(sg.in && sg.out && sg.nrows > 0 && sg.width > 0 && sg.stride >= sg.width, "xp_reduce_rows_batch: bad segment %d", i);
+    a.seg[i] = sg; a.part2[i] = ws; a.cb0[i] = cb;
+    ws += (size_t)32 * sg.width;
+    cb += (int)cdiv(sg.width, 64);
+    any_l1 = any_l1 || sg.nrows > RB_DIRECT;
+  }
+  for (int i = n; i <= XP_REDUCE_MAX_SEGS; ++i) a.cb0[i] = cb;
+  hipStream_t st = (hipStream_t)stream;
+  if (any_l1) {
+    reduce_batch_l1_kernel<<<dim3((unsigned)cb, 32), 256, 0, st>>>(a);
+    XP_CHECK_LAUNCH("xp_reduce_rows_batch(level 1)");
+  }
+  reduce_batch_l2_kernel<<<(unsigned)cb, 256, 0, st>>>(a);
+  XP_CHECK_LAUNCH("xp_reduce_rows_batch(level 2)");
   return XP_OK;
 }
 

@@ -216,6 +216,8 @@ extern "C" int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
   return XP_OK;
 }
 
+extern "C" int64_t xp_layernorm_bwd_partial_rows(int64_t rows) { return bwd_blocks(rows); }
+
 extern "C" size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
   return (size_t)(bwd_blocks(rows) + 32) * 2 * cols * sizeof(float);
 }
@@ -225,7 +227,8 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                                 void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                                 int64_t rows, int64_t cols, int32_t dtype,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-  XP_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "xp_layernorm_bwd: null pointer");
+  XP_REQUIRE(dy && x && gamma && mean && rstd && dx, "xp_layernorm_bwd: null pointer");
+  XP_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), "xp_layernorm_bwd: dgamma and dbeta must both be given or both be NULL");
   XP_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXJ * 256, "xp_layernorm_bwd: cols=%lld unsupported", (long long)cols);
   XP_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "xp_layernorm_bwd: ld must be a multiple of 4");
   XP_REQUIRE(workspace && workspace_bytes >= xp_layernorm_bwd_workspace_bytes(rows, cols), "xp_layernorm_bwd: workspace too small");
@@ -241,6 +244,7 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
   else                  { if (nj == 1) XP_LN_BWD(float, 1);  else if (nj == 2) XP_LN_BWD(float, 2);  else if (nj == 3) XP_LN_BWD(float, 3);  else XP_LN_BWD(float, 4); }
 #undef XP_LN_BWD
   XP_CHECK_LAUNCH("xp_layernorm_bwd");
+  if (!dgamma) return XP_OK;       // deferred: the caller reduces the partial rows (xp_reduce_rows_batch)
   // two-level deterministic reduce of the per-block partial rows: blocks -> <=32 -> 1; dgamma/dbeta may be two
   // separate buffers, so the last level runs once per output
   const int width = 2 * (int)cols, lvl = (int)cdiv(blocks, 32);

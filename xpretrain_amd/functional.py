@@ -201,23 +201,25 @@ class EncoderLayerFn(torch.autograd.Function):
         B, S, heads, size, q_scale, D, Dff = ctx.meta
         rows = x.shape[0]
         dx3 = dx3.contiguous()
+        defer = H.DeferredReduce(x.device)       # the 4 bias + 4 LayerNorm-parameter reductions finish in 2 launches
         # ---- MLP: x3 = x2 + fc2(quick_gelu(fc1(LN2(x2))))
         dpre = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre)
         dw2 = _wgrad(dx3, act, rows, D, Dff)
-        db2 = H.colsum(dx3, rows, D)
+        db2 = H.colsum_deferred(dx3, rows, D, defer)
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
         dw1 = _wgrad(dpre, h2, rows, Dff, D)
-        db1 = H.colsum(dpre, rows, Dff)
-        dx2, dln2_w, dln2_b = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3)
+        db1 = H.colsum_deferred(dpre, rows, Dff, defer)
+        dx2, dln2_w, dln2_b = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer)
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
         dwo = _wgrad(dx2, attn_o, rows, D, D)
-        dbo = H.colsum(dx2, rows, D)
+        dbo = H.colsum_deferred(dx2, rows, D, defer)
         dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
         dh1 = H.gemm(dqkv, Wqkv, rows, D, 3 * D, b_kstrided=True)
         dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)
-        dbqkv = H.colsum(dqkv, rows, 3 * D)
-        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2)
+        dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer)
+        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer)
+        defer.flush()
         dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
         return (dx, dln1_w, dln1_b, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dln2_w, dln2_b, dw1, db1, dw2, db2,

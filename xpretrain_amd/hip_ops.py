@@ -127,6 +127,52 @@ def colsum(X: torch.Tensor, rows: int, cols: int, ldx=None, out=None, accumulate
     return out
 
 
+class DeferredReduce:
+    """Collects the second-level reductions of several bias / LayerNorm-parameter gradients and finishes them in two
+    launches (xp_reduce_rows_batch).  Each deferred producer keeps its partial rows in its own workspace slot."""
+
+    def __init__(self, device):
+        self.device = device
+        self.segs = []
+        self._keep = []
+
+    def add(self, part: torch.Tensor, part_offset: int, out: torch.Tensor, nrows: int, width: int, stride: int,
+            accumulate=False):
+        sg = L.XpReduceSeg()
+        sg.in_ = part.data_ptr() + 4 * part_offset
+        sg.out = out.data_ptr()
+        sg.stride, sg.nrows, sg.width, sg.accumulate = stride, nrows, width, int(accumulate)
+        self.segs.append(sg)
+        self._keep.append((part, out))
+
+    def slot(self, nbytes: int) -> torch.Tensor:
+        return workspace(nbytes, self.device, f"defer{len(self._keep)}")
+
+    def flush(self):
+        if not self.segs:
+            return
+        lib = L.lib()
+        for i in range(0, len(self.segs), L.XP_REDUCE_MAX_SEGS):
+            chunk = self.segs[i:i + L.XP_REDUCE_MAX_SEGS]
+            arr = (L.XpReduceSeg * len(chunk))(*chunk)
+            nb = lib.xp_reduce_rows_batch_workspace_bytes(arr, len(chunk))
+            ws = workspace(nb, self.device, "reduce_batch")
+            L.check(lib.xp_reduce_rows_batch(arr, len(chunk), _p(ws), ws.numel(), _stream()), "xp_reduce_rows_batch")
+        self.segs, self._keep = [], []
+
+
+def colsum_deferred(X: torch.Tensor, rows: int, cols: int, defer: DeferredReduce, ldx=None) -> torch.Tensor:
+    """Bias gradient whose final reduction is finished by ``defer.flush()``."""
+    _chk(X, "X")
+    out = torch.empty(cols, dtype=torch.float32, device=X.device)
+    chunks = L.lib().xp_colsum_partial_rows(rows)
+    part = defer.slot(chunks * cols * 4)
+    L.check(L.lib().xp_colsum_partials(_p(X), rows, cols, ldx or cols, _dt(X), _p(part), part.numel(), _stream()),
+            "xp_colsum_partials")
+    defer.add(part, 0, out, chunks, cols, cols)
+    return out
+
+
 # --------------------------------------------------------------------------------------- LayerNorm
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows: int, cols: int, ldx=None,
                   eps: float = 1e-5):
@@ -140,12 +186,21 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, dres=None, dx=None, lddx=None,
-                  dgamma=None, dbeta=None, accumulate=False):
+                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None):
     _chk(dy, "dy"); _chk(x, "x", dy.dtype)
     dx = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device) if dx is None else dx
     dgamma = torch.empty(cols, dtype=torch.float32, device=dy.device) if dgamma is None else dgamma
     dbeta = torch.empty(cols, dtype=torch.float32, device=dy.device) if dbeta is None else dbeta
     nb = L.lib().xp_layernorm_bwd_workspace_bytes(rows, cols)
+    if defer is not None:     # parameter-gradient partial rows stay in their own slot until defer.flush()
+        ws = defer.slot(nb)
+        L.check(L.lib().xp_layernorm_bwd(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
+                                         _p(dres), cols, _p(dx), lddx or cols, None, None, 0,
+                                         rows, cols, _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd")
+        nrows = L.lib().xp_layernorm_bwd_partial_rows(rows)
+        defer.add(ws, 0, dgamma, nrows, cols, 2 * cols, accumulate)
+        defer.add(ws, cols, dbeta, nrows, cols, 2 * cols, accumulate)
+        return dx, dgamma, dbeta
     ws = workspace(nb, dy.device, "ln")
     L.check(L.lib().xp_layernorm_bwd(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
                                      _p(dres), cols, _p(dx), lddx or cols, _p(dgamma), _p(dbeta), int(accumulate),
