@@ -155,6 +155,12 @@ int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dou
  */
 /* frames fp32 [BT,3,H,W] -> patch matrix [BT*gh*gw, 3*P*P] (dtype), k = (c,py,px): the conv-as-GEMM A operand */
 int xp_im2col(const float* video, void* patches, int64_t BT, int64_t H, int64_t W, int64_t P, int32_t dtype, void* stream);
+/* Same patch matrix straight from DECODED uint8 frames [BT,3,H,W]: (x/255 - mean[c]) / std[c] -- the host collate's
+ * /255 + transforms.Normalize (datasets/dataloader.py:209-233) resp. ImageNorm on the device
+ * (datasets/data_utils.py:256-281) -- fused with the cast and the patch gather.  mean/std: HOST
+ * float[3]. */
+int xp_im2col_u8(const uint8_t* frames, const float* mean3_host, const float* std3_host, void* patches, int64_t BT,
+                 int64_t H, int64_t W, int64_t P, int32_t dtype, void* stream);
 /* proxy rows: x[b, 0] = class_emb + pos[0]; x[b, 1+i] = added_cls[i] + pos[0]   (:187-191) */
 int xp_vip_proxy_rows(const float* class_emb, const float* added_cls, const float* pos, void* x,
                       int64_t B, int64_t S, int64_t M, int64_t D, int32_t dtype, void* stream);
@@ -238,11 +244,27 @@ int xp_vsc_fc_loss(const float* vis, const float* txt, const float* img, const f
                    float* loss, float* d_vis, float* d_txt, float* d_img, float* d_cap, float* d_log_scale,
                    int64_t n, int64_t d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------- Retrieval evaluation
+ * validate() of tasks/run_video_retrieval.py:123-203 on gathered unit-norm features (fp32):
+ *   sim = text . vis^T                     cal_cossim, utils/metrics.py:3-5
+ *   sim *= softmax(theta * sim, axis 0)    DSL re-rank, run_video_retrieval.py:170-171 / np_softmax metrics.py:7-39
+ *                                          (multiply == 0: sim = softmax(theta * sim, axis 0) only)
+ *   rank of each query's labelled entry    compute_metrics / compute_metrics_multi, metrics.py:41-69
+ * xp_retrieval_ranks: query i = row i (transpose = 0) or column i (transpose != 0, the v2t direction, which the
+ * reference evaluates on sim.T); label = labels[i] or i; greater[i] / equal[i] = number of candidates with a score
+ * above / equal to the labelled one (the label sits at sorted positions greater .. greater+equal-1). */
+int xp_sim_matrix(const float* a, const float* b, float* sim, int64_t na, int64_t nb, int64_t d, void* stream);
+int xp_dsl_rerank(float* sim, int64_t n, int64_t m, float theta, int32_t multiply, void* stream);
+int xp_retrieval_ranks(const float* sim, const int64_t* labels, int64_t n, int64_t m, int32_t transpose,
+                       int32_t* greater, int32_t* equal, void* stream);
+
 /* -------------------------------------------------------------------------------------- Diagnostics
  * Hardware-layout probes used by tests/test_probe_gpu.py to pin the MFMA / LDS-transpose lane maps
  * this library relies on (out buffers are small device arrays; see csrc/probe.hip). */
 /* cycle-stamp trace of the 128x128 GEMM main loop (tools/gemm_trace.py); pass NULL to disable.  buffer: >= 1 KiB */
 int xp_debug_set_gemm_trace(void* device_buffer);
+/* cycle stamps of one attention-forward workgroup (start, loads issued, loads landed, loop end); NULL disables */
+int xp_debug_set_attn_trace(void* device_buffer);
 /* resident workgroups per CU of the default bf16 GEMM kernel at `lds_bytes` of dynamic LDS (occupancy API) */
 int xp_debug_gemm_occupancy(int lds_bytes);
 int xp_probe_mfma_bf16(const void* a, const void* b, float* c, void* stream);

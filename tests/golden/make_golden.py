@@ -19,6 +19,8 @@ Fixtures (all fp32, CPU, torch.manual_seed'ed):
   temporal_interp.pt CLIPVisionViPEmbeddings for T in {1,8,12,32} (temporal_size 12).
   loss.pt            NCELearnableTempLoss / NCELearnableTempLoss_vsc_fc for several batch sizes
                      and logit scales (incl. both clamp limits 0 and ln 200).
+  retrieval.pt       src/utils/metrics.py (cal_cossim, np_softmax, compute_metrics, compute_metrics_multi) in the simple
+                     and DSL settings of validate(), incl. exact score ties; ImageNorm arithmetic on uint8 frames.
   optim.pt           src/optimization: AdamW.step x 6 with clip_grad_norm_ 5.0 and the warmup-cosine schedule
                      over the four build_e2e_optimizer_w_lr_mul groups; get_lr_sched tables.
 """
@@ -237,10 +239,48 @@ def optim(ref):
     print("optim: steps", steps, "norms", [round(float(n), 3) for n in norms])
 
 
+def retrieval(ref):
+    """src/utils/metrics.py on seeded feature sets: plain, with exact duplicate captions (ties), multi-label."""
+    import importlib
+    import numpy as np
+    metrics = importlib.import_module("src.utils.metrics")
+    rng = np.random.RandomState(5)
+    cases = []
+    for n, d, noise, dup in [(64, 32, 1.5, 0), (200, 64, 2.2, 0), (333, 48, 2.5, 0), (96, 16, 0.8, 7)]:
+        vis = rng.randn(n, d).astype(np.float32)
+        txt = vis + noise * rng.randn(n, d).astype(np.float32)
+        if dup:                                   # duplicated videos: exact score ties in every text row
+            vis[n - dup:] = vis[:dup]
+        vis /= np.linalg.norm(vis, axis=1, keepdims=True)
+        txt /= np.linalg.norm(txt, axis=1, keepdims=True)
+        sim = metrics.cal_cossim(txt, vis)
+        res = {}
+        s2 = sim
+        for setting in ("simple", "DSL"):
+            if setting == "DSL":
+                s2 = s2 * metrics.np_softmax(s2 * 100, axis=0)        # run_video_retrieval.py:170-171
+            res[setting] = dict(v2t=metrics.compute_metrics(s2.T), t2v=metrics.compute_metrics(s2))
+        labels = rng.randint(0, n, size=n)
+        cases.append(dict(txt=torch.from_numpy(txt), vis=torch.from_numpy(vis),
+                          sim=torch.from_numpy(sim) if n <= 96 else None,
+                          softmax100=torch.from_numpy(metrics.np_softmax(sim * 100, axis=0)) if n <= 96 else None, results=res,
+                          labels=torch.from_numpy(labels), multi=metrics.compute_metrics_multi(sim, labels.tolist())))
+    # ImageNorm on the device (data_utils.py:256-281) is CUDA-only; its arithmetic is three in-place tensor ops, run here
+    # on CPU tensors with the same operation order: div_(255.), sub_(mean), div_(std)
+    g = torch.Generator().manual_seed(8)
+    frames = torch.randint(0, 256, (2, 3, 3, 32, 32), generator=g, dtype=torch.uint8)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    img = frames.float()
+    img.div_(255.)
+    img = img.sub_(torch.tensor(mean).view(1, 1, 3, 1, 1)).div_(torch.tensor(std).view(1, 1, 3, 1, 1))
+    torch.save(dict(cases=cases, frames=frames, normed=img, mean=mean, std=std), os.path.join(HERE, "retrieval.pt"))
+    print("retrieval:", [(c["results"]["simple"]["t2v"][0], c["results"]["DSL"]["t2v"][0]) for c in cases])
+
+
 if __name__ == "__main__":
     ref = ref_import.load()
-    if len(sys.argv) > 1 and sys.argv[1] == "optim":
-        optim(ref)
+    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "retrieval"):
+        {"optim": optim, "retrieval": retrieval}[sys.argv[1]](ref)
         sys.exit(0)
     tiny_e2e(ref)
     attn_forward2(ref)
@@ -248,6 +288,7 @@ if __name__ == "__main__":
     temporal_interp(ref)
     loss(ref)
     optim(ref)
+    retrieval(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

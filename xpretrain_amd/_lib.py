@@ -83,6 +83,7 @@ SIGNATURES = {
     "xp_attn_fwd": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
     "xp_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
     "xp_im2col": (i32, [vp, vp, i64, i64, i64, i64, i32, vp]),
+    "xp_im2col_u8": (i32, [vp, C.POINTER(f32), C.POINTER(f32), vp, i64, i64, i64, i64, i32, vp]),
     "xp_vip_proxy_rows": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]),
     "xp_vip_embed_bwd_workspace_bytes": (sz, [i64, i64, i64, i64]),
     "xp_vip_embed_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, vp, sz, vp]),
@@ -97,9 +98,13 @@ SIGNATURES = {
     "xp_cast_back": (i32, [vp, vp, i64, i32, i32, vp]),
     "xp_nce_loss_workspace_bytes": (sz, [i64, i64]),
     "xp_nce_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, sz, vp]),
+    "xp_sim_matrix": (i32, [vp, vp, vp, i64, i64, i64, vp]),
+    "xp_dsl_rerank": (i32, [vp, i64, i64, f32, i32, vp]),
+    "xp_retrieval_ranks": (i32, [vp, vp, i64, i64, i32, vp, vp, vp]),
     "xp_vsc_fc_loss_workspace_bytes": (sz, [i64, i64]),
     "xp_vsc_fc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, sz, vp]),
     "xp_debug_set_gemm_trace": (i32, [vp]),
+    "xp_debug_set_attn_trace": (i32, [vp]),
     "xp_debug_gemm_occupancy": (i32, [i32]),
     "xp_probe_mfma_bf16": (i32, [vp, vp, vp, vp]),
     "xp_probe_mfma_f32": (i32, [vp, vp, vp, vp]),

@@ -41,6 +41,7 @@ struct AP {
   float* stats;
   const int64_t* pad;
   int mode, B, H, S, M, N, L, R;
+  int nq, nprob;                        // forward: query blocks per problem, problems
   float q_scale;
   float* ws0; float* ws1; float* ws2;   // fwd: partials | bwd: delta, dq partials, dkv partials
 };
@@ -166,12 +167,145 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 constexpr int PART = 2 + DH;   // forward proxy partial: m, l, O[64]
 
 // ============================================================================================ forward
-__global__ __launch_bounds__(NTHR) void attn_fwd_kernel(AP p) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + GR];
-  char* gK = smem; char* gV = smem + 4 * TILE; unsigned char* gPad = reinterpret_cast<unsigned char*>(smem + 8 * TILE);
+// Forward workgroup: 7 waves x 16 query rows = 112 rows of one problem against ALL its keys.  Keys/values are staged in
+// LDS in groups of up to 208 rows (13 sixteen-row sub-tiles = a whole ViT-B/16 frame problem, 52 KiB), so three
+// workgroups fit a CU and one workgroup's global loads / dispatch overlap the others' softmax (the loop is VALU-bound:
+// ~16 cycles per exp per wave).  The tail is processed at 16-key granularity (a 16x16x16 MFMA takes an odd sub-tile):
+// R = 200 costs 13 sub-tiles, not 16.  The query blocks of one problem get workgroup ids 8 apart: same XCD (shared
+// L2 lines for the second K/V fetch), adjacent in dispatch order.
+constexpr int FW = 7, FTHR = FW * 64, FQ = FW * 16;
+constexpr int FG = 208;                                  // key rows per LDS group
+constexpr int F_LDS = 2 * FG * 128 + FG;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ s16x4 pack_p4(f32x4 a) {
+  const bf16x4 v = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+  return __builtin_bit_cast(s16x4, v);
+}
+// A fragment of the transposed tile for ONE 16-row sub-tile (16x16x16 MFMA): rows = d, k-slot e -> row sub*16 + 4g + e
+__device__ __forceinline__ s16x4 frag_cols16(const char* tile, int dt, int sub, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int r0 = sub * 16 + 4 * g + (i >> 2);
+  return __builtin_bit_cast(s16x4, lds_read_tr16(tile + tile128_off(r0, dt * 2 + ((i & 3) >> 1)) + ((i & 1) << 3)));
+}
+
+// cooperative load of key rows [row0, row0 + nrows) of K AND V (same rows, V = K + voff_v bytes) into the linear swizzled
+// images.  Branch-free: buffer loads relative to the sample's first token, rows >= R (or >= nrows) get an out-of-range
+// offset and read as zero.
+__device__ __forceinline__ void fwd_load_kv(char* gK, char* gV, __amdgpu_buffer_rsrc_t rs, unsigned ld_bytes, unsigned voff_v,
+                                            const AP& p, const Prob& pr, int row0, int nrows, int tid) {
+  constexpr int NJ = (FG * 8 + FTHR - 1) / FTHR;
+  u32x4 vk[NJ], vv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = tid + j * FTHR, row = e >> 3, c = e & 7, r = row0 + row;
+    const unsigned off = (row < nrows && r < p.R) ? (unsigned)tok_of(p, pr.n, r) * ld_bytes + c * 16 : 0xFFFFFF00u;
+    vk[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    vv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, voff_v, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = tid + j * FTHR, row = e >> 3, c = e & 7;
+    if (row < FG) {
+      *reinterpret_cast<u32x4*>(gK + tile128_off(row, c)) = vk[j];
+      *reinterpret_cast<u32x4*>(gV + tile128_off(row, c)) = vv[j];
+    }
+  }
+}
+
+struct FwdState { f32x4 o[4]; float m, l; };
+
+// The masked score path as a real call: inlined into the step loops its sixteen (sub-tile, slot) predicates are hoisted
+// out of the key loop as loop invariants and spill; it runs on the tail step / causal band / proxy corner only.
+struct S16 { f32x4 s[4]; };
+__device__ __attribute__((noinline)) S16 fwd_mask_scores(S16 v, int ns, const unsigned char* pad, int R, int M, int mode, int n,
+                                                         int rq, int qvalid, int kb, int g) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kl = t * 16 + 4 * g + r, rk = kb + kl;
+      float x = v.s[t][r];
+      if (t < ns) {
+        if (pad[kl]) x = F32_MIN;
+        const bool ok = mode == XP_ATTN_PROXY ? !(rq < M && rk < M && n != 0) : rk <= rq;
+        if (!(qvalid && rk < R && ok)) x = -INFINITY;
+      }
+      v.s[t][r] = x;
+    }
+  return v;
+}
+
+// one step over NS (1..4) sixteen-key sub-tiles starting at LDS row t0*16 (global key row kb)
+template <int NS>
+__device__ __forceinline__ void fwd_step(FwdState& st, const AP& p, const Prob& pr, const char* gK, const char* gV,
+                                         const unsigned char* gPad, const bf16x8 (&qf)[2], int t0, int kb, int rq,
+                                         bool qvalid, int wrow0, int lane) {
+  const int g = lane >> 4;
+  f32x4 s[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    s[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) s[t] = mma16(frag_rows(gK, t0 + t, kk, lane), qf[kk], s[t]);
+  }
+  float tmax = -INFINITY;
+  // masking is only needed (wave-uniformly) where the step touches rows >= R, with a padding mask, on the causal
+  // diagonal band, or where proxy rows meet proxy keys in a frame n != 0
+  const bool need_mask = kb + NS * 16 > p.R || p.pad != nullptr ||
+      (p.mode == XP_ATTN_CAUSAL ? kb + NS * 16 - 1 > wrow0 : (pr.n != 0 && kb < p.M && wrow0 < p.M));
+  if (need_mask) {
+    S16 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v.s[t] = t < NS ? s[t < NS ? t : 0] : f32x4{0, 0, 0, 0};
+    v = fwd_mask_scores(v, NS, gPad + t0 * 16, p.R, p.M, p.mode, pr.n, rq, qvalid ? 1 : 0, kb, g);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) s[t] = v.s[t];
+  }
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[t][r]);
+  tmax = group_max(tmax);
+  const float mnew = fmaxf(st.m, tmax);
+  const float msafe = mnew == -INFINITY ? 0.f : mnew;
+  const float alpha = __expf(st.m - msafe);          // m = -inf -> 0
+  float psum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float e = __expf(s[t][r] - msafe); s[t][r] = e; psum += e; }
+  st.l = st.l * alpha + psum;
+  st.m = mnew;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) st.o[dt] *= alpha;
+  const char* sV = gV + t0 * 16 * 128;               // row shift by a multiple of 16 keeps the swizzle phase
+#pragma unroll
+  for (int c = 0; c < NS / 2; ++c) {
+    const bf16x8 pf = pack_p(s[2 * c], s[2 * c + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.o[dt] = mma16(frag_cols(sV, dt, c, lane), pf, st.o[dt]);
+  }
+  if constexpr (NS & 1) {
+    const s16x4 pf = pack_p4(s[NS - 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      st.o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(frag_cols16(sV, dt, NS - 1, lane), pf, st.o[dt], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(FTHR, 4) void attn_fwd_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[F_LDS];
+  char* gK = smem; char* gV = smem + FG * 128; unsigned char* gPad = reinterpret_cast<unsigned char*>(smem + 2 * FG * 128);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-  const Prob pr(p, blockIdx.y);
-  const int qb = blockIdx.x * TQ;
+  const int slot = blockIdx.x >> 3;
+  const int prob = (slot / p.nq) * 8 + (blockIdx.x & 7);
+  if (prob >= p.nprob) return;
+  const Prob pr(p, prob);
+  const int qb = (slot % p.nq) * FQ;
+  unsigned long long* tr = (p.mode == XP_ATTN_PROXY && p.ws2 && prob == p.nprob / 2 && qb == 0 && tid == 0)
+                               ? reinterpret_cast<unsigned long long*>(p.ws2) : nullptr;      // xp_debug_set_attn_trace
+  if (tr) tr[0] = __builtin_amdgcn_s_memtime();
   const int rq = qb + wave * 16 + i16;            // this lane's query row (column of S^T)
   const bool qvalid = rq < p.R;
   const int64_t qtok = (int64_t)pr.b * p.S + tok_of(p, pr.n, qvalid ? rq : 0);
@@ -179,99 +313,58 @@ __global__ __launch_bounds__(NTHR) void attn_fwd_kernel(AP p) {
   bf16x8 qf[2];
   load_row_frag(qf, p.qkv + qtok * p.ldqkv + pr.h * DH, qvalid, g);
 
-  f32x4 o[4];
+  FwdState st;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
-  float m = -INFINITY, l = 0.f;
+  for (int dt = 0; dt < 4; ++dt) st.o[dt] = f32x4{0, 0, 0, 0};
+  st.m = -INFINITY; st.l = 0.f;
 
-  int ntiles = (p.R + 63) / 64;
-  if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
+  int nsub = (p.R + 15) / 16;                     // sixteen-key sub-tiles this workgroup visits
+  if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + FQ - 1) / 16 + 1; nsub = nsub < lim ? nsub : lim; }
 
-  const int64_t kcol = (int64_t)p.H * DH + pr.h * DH, vcol = (int64_t)2 * p.H * DH + pr.h * DH;
-  const bool wave_active = qb + wave * 16 < p.R;        // wave-uniform: waves past the last row only keep the barriers
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int kb = kt * 64;
-    if ((kt & 3) == 0) {                                // new key group: ONE load phase for up to 4 tiles
-      if (kt) __syncthreads();
-      const int nt = ntiles - kt < 4 ? ntiles - kt : 4;
-      load_group(gK, p.qkv, p.ldqkv, kcol, p, pr, kb, nt, tid);
-      load_group(gV, p.qkv, p.ldqkv, vcol, p, pr, kb, nt, tid);
-      if (tid < GR) { const int r = kb + tid; gPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0; }
-      __syncthreads();
-    }
+  // K slice of head h of this sample's first token; V is H*DH elements further
+  const bf16_t* kbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + (int64_t)p.H * DH + pr.h * DH;
+  const unsigned ld_bytes = (unsigned)(p.ldqkv * 2);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (unsigned)((int64_t)p.S * p.ldqkv * 2 - ((int64_t)p.H * DH + pr.h * DH) * 2), 0x00020000);
+  const unsigned voff_v = (unsigned)(p.H * DH * 2);
+  const int wrow0 = qb + wave * 16;
+  const bool wave_active = wrow0 < p.R;           // wave-uniform: waves past the last row only keep the barriers
+  for (int g0 = 0; g0 < nsub; g0 += FG / 16) {
+    const int ng = nsub - g0 < FG / 16 ? nsub - g0 : FG / 16;
+    if (g0) __syncthreads();
+    fwd_load_kv(gK, gV, rs, ld_bytes, voff_v, p, pr, g0 * 16, ng * 16, tid);
+    if (tid < FG) { const int r = g0 * 16 + tid; gPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0; }
+    if (tr && g0 == 0) tr[1] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (tr && g0 == 0) tr[2] = __builtin_amdgcn_s_memtime();
     if (!wave_active) continue;
-    const char* sK = gK + (kt & 3) * TILE;
-    const char* sV = gV + (kt & 3) * TILE;
-    const unsigned char* sPad = gPad + (kt & 3) * 64;
-
-    f32x4 s[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) s[t] = mma16(frag_rows(sK, t, kk, lane), qf[kk], s[t]);
-    }
-    float tmax = -INFINITY;
-    // masking is only needed (wave-uniformly) on the tail tile, with a padding mask, on the causal diagonal band, or
-    // where proxy rows meet proxy keys in a frame n != 0 -- every other (wave, tile) pair takes the mask-free path
-    // (the mask logic was ~half of this kernel's VALU work).  Lanes of invalid query rows compute discarded values.
-    const int wrow0 = qb + wave * 16;
-    const bool need_mask = kb + 64 > p.R || p.pad != nullptr ||
-        (p.mode == XP_ATTN_CAUSAL ? kb + 63 > wrow0 : (pr.n != 0 && kb < p.M && wrow0 < p.M));
-    if (need_mask) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kl = t * 16 + 4 * g + r, rk = kb + kl;
-          float v = s[t][r];
-          if (sPad[kl]) v = F32_MIN;
-          if (!(qvalid && rk < p.R && allowed(p, pr.n, rq, rk))) v = -INFINITY;
-          s[t][r] = v;
-          tmax = fmaxf(tmax, v);
-        }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[t][r]);
-    }
-    tmax = group_max(tmax);
-    const float mnew = fmaxf(m, tmax);
-    const float msafe = mnew == -INFINITY ? 0.f : mnew;
-    const float alpha = __expf(m - msafe);          // m = -inf -> 0
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = __expf(s[t][r] - msafe); s[t][r] = e; psum += e; }
-    l = l * alpha + psum;
-    m = mnew;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-    const bf16x8 pf0 = pack_p(s[0], s[1]), pf1 = pack_p(s[2], s[3]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      o[dt] = mma16(frag_cols(sV, dt, 0, lane), pf0, o[dt]);
-      o[dt] = mma16(frag_cols(sV, dt, 1, lane), pf1, o[dt]);
+    for (int t0 = 0; t0 < ng; t0 += 4) {
+      const int ns = ng - t0 < 4 ? ng - t0 : 4;
+      const int kb = (g0 + t0) * 16;
+      // two instantiations only (register pressure): a 2- or 3-sub-tile tail runs the 4-wide step with its surplus keys
+      // masked (rows < FG of the images are always written -- zeros past the group -- and t0 <= 8 here)
+      if (ns == 1) fwd_step<1>(st, p, pr, gK, gV, gPad, qf, t0, kb, rq, qvalid, wrow0, lane);
+      else         fwd_step<4>(st, p, pr, gK, gV, gPad, qf, t0, kb, rq, qvalid, wrow0, lane);
     }
   }
-  l = group_sum(l);
+  const float m = st.m;
+  const float l = group_sum(st.l);
+  if (tr) tr[3] = __builtin_amdgcn_s_memtime();
   if (!qvalid) return;
   if (p.mode == XP_ATTN_PROXY && rq < p.M) {
-    float* part = p.ws0 + ((int64_t)blockIdx.y * p.M + rq) * PART;
+    float* part = p.ws0 + ((int64_t)prob * p.M + rq) * PART;
     if (g == 0) { part[0] = m; part[1] = l; }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store4(part + 2 + dt * 16 + 4 * g, o[dt]);
+    for (int dt = 0; dt < 4; ++dt) store4(part + 2 + dt * 16 + 4 * g, st.o[dt]);
     return;
   }
   const float inv = 1.0f / l;
   bf16_t* orow = p.out + qtok * p.ldo + pr.h * DH;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + 4 * g, o[dt] * inv);
+  for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + 4 * g, st.o[dt] * inv);
   if (g == 0) {
-    float* st = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, rq)) * 2;
-    st[0] = m; st[1] = __logf(l);
+    float* sp = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, rq)) * 2;
+    sp[0] = m; sp[1] = __logf(l);
   }
 }
 
@@ -541,6 +634,9 @@ int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S
 
 }  // namespace
 
+static void* g_attn_trace = nullptr;
+extern "C" int xp_debug_set_attn_trace(void* device_buffer) { g_attn_trace = device_buffer; return XP_OK; }
+
 extern "C" size_t xp_attn_workspace_bytes(int32_t mode, int64_t B, int64_t H, int64_t M, int64_t N, int64_t L) {
   // S is M + N*L for PROXY; for CAUSAL callers pass M=0, N=1, L=S
   const int64_t S = M + N * L;
@@ -566,9 +662,10 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   p.mode = mode; p.B = (int)B; p.H = (int)H; p.S = (int)S; p.M = (int)M; p.N = (int)N; p.L = (int)L;
   p.R = mode == XP_ATTN_PROXY ? (int)(M + L) : (int)S;
   p.ws0 = (float*)workspace;
+  p.ws2 = (float*)g_attn_trace;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)cdiv(p.R, TQ), (unsigned)(B * H * N));
-  attn_fwd_kernel<<<grid, NTHR, 0, st>>>(p);
+  p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)(B * H * N);
+  attn_fwd_kernel<<<(unsigned)(cdiv(p.nprob, 8) * 8 * p.nq), FTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_fwd");
   if (mode == XP_ATTN_PROXY) {
     attn_fwd_merge_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);

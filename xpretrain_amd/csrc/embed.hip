@@ -27,6 +27,34 @@ __global__ void im2col_kernel(const float* __restrict__ v, T* __restrict__ out, 
   }
 }
 
+// ---- im2col straight from decoded uint8 frames [BT,3,H,W]: (x / 255 - mean[c]) / std[c] (the collate / ImageNorm
+// arithmetic, datasets/dataloader.py:209-233, data_utils.py:256-281) fused with the cast and the patch gather: the
+// frame read drops from 4 B to 1 B per pixel.  8 consecutive px (8 bytes) per thread.
+struct Norm3 { float mean[3], std[3]; };
+template <typename T>
+__global__ void im2col_u8_kernel(const unsigned char* __restrict__ v, T* __restrict__ out, int64_t BT, int H, int W, int P, Norm3 nm) {
+  const int gh = H / P, gw = W / P, K = 3 * P * P, KC = K / 8;
+  const int64_t total = BT * gh * gw * KC;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / KC;
+    const int k = (int)(idx % KC) * 8;
+    const int c = k / (P * P), py = (k % (P * P)) / P, px = k % P;
+    const int64_t bt = m / (gh * gw);
+    const int gy = (int)((m % (gh * gw)) / gw), gx = (int)(m % gw);
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(v + ((bt * 3 + c) * H + gy * P + py) * (int64_t)W + gx * P + px);
+    const float mean = nm.mean[c], sd = nm.std[c];
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // same operation order as the reference: divide by 255, subtract the mean, divide by the std
+      a[e] = ((float)((raw[0] >> (8 * e)) & 0xFF) / 255.0f - mean) / sd;
+      b[e] = ((float)((raw[1] >> (8 * e)) & 0xFF) / 255.0f - mean) / sd;
+    }
+    T* dst = out + m * K + k;
+    store4(dst, a); store4(dst + 4, b);
+  }
+}
+
 // ---- proxy rows: x[b,0] = class + pos[0]; x[b,1+i] = added[i] + pos[0] ----------------------------------
 template <typename T>
 __global__ void vip_proxy_rows_kernel(const float* __restrict__ cls, const float* __restrict__ added,
@@ -225,6 +253,25 @@ extern "C" int xp_im2col(const float* video, void* patches, int64_t BT, int64_t 
   DISPATCH(dtype, (im2col_kernel<bf16_t><<<g, TPB, 0, st>>>(video, (bf16_t*)patches, BT, (int)H, (int)W, (int)P)),
            (im2col_kernel<float><<<g, TPB, 0, st>>>(video, (float*)patches, BT, (int)H, (int)W, (int)P)), "xp_im2col");
   XP_CHECK_LAUNCH("xp_im2col");
+  return XP_OK;
+}
+
+extern "C" int xp_im2col_u8(const uint8_t* frames, const float* mean3_host, const float* std3_host, void* patches, int64_t BT,
+                            int64_t H, int64_t W, int64_t P, int32_t dtype, void* stream) {
+  XP_REQUIRE(frames && patches && mean3_host && std3_host && BT > 0, "xp_im2col_u8: null/empty");
+  XP_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0, "xp_im2col_u8: need P%%8==0 and H,W multiples of P (H=%lld W=%lld P=%lld)",
+             (long long)H, (long long)W, (long long)P);
+  XP_REQUIRE(((uintptr_t)frames & 7) == 0, "xp_im2col_u8: frames must be 8-byte aligned");
+  Norm3 nm;
+  for (int c = 0; c < 3; ++c) {
+    XP_REQUIRE(std3_host[c] > 0.f, "xp_im2col_u8: std[%d] must be positive", c);
+    nm.mean[c] = mean3_host[c]; nm.std[c] = std3_host[c];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for(BT * (H / P) * (W / P) * (3 * P * P / 8));
+  DISPATCH(dtype, (im2col_u8_kernel<bf16_t><<<g, TPB, 0, st>>>(frames, (bf16_t*)patches, BT, (int)H, (int)W, (int)P, nm)),
+           (im2col_u8_kernel<float><<<g, TPB, 0, st>>>(frames, (float*)patches, BT, (int)H, (int)W, (int)P, nm)), "xp_im2col_u8");
+  XP_CHECK_LAUNCH("xp_im2col_u8");
   return XP_OK;
 }
 

@@ -158,7 +158,67 @@ __global__ void vsc_grad_kernel(const float* __restrict__ S1, const float* __res
   }
 }
 
+// ---- retrieval evaluation (tasks/run_video_retrieval.py:150-171, utils/metrics.py) --------------------------------
+// DSL re-rank: sim[i][j] *= softmax_i(theta * sim[i][j])   (np_softmax(sim * 100, axis=0), metrics.py:7-39); one wave per column
+__global__ void dsl_rerank_kernel(float* __restrict__ sim, int n, int m, float theta, int multiply) {
+  const int lane = threadIdx.x, j = blockIdx.x;
+  float mx = -INFINITY;
+  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sim[(int64_t)i * m + j] * theta);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int i = lane; i < n; i += 64) sum += expf(sim[(int64_t)i * m + j] * theta - mx);
+  sum = wave_sum(sum);
+  for (int i = lane; i < n; i += 64) {
+    const float x = sim[(int64_t)i * m + j];
+    const float sm = expf(x * theta - mx) / sum;
+    sim[(int64_t)i * m + j] = multiply ? x * sm : sm;
+  }
+}
+
+// per query row i: how many entries beat / tie the labelled entry (compute_metrics: position of the label in the
+// descending sort, metrics.py:41-53; ties occupy `equal` consecutive positions there).  transpose != 0 ranks columns.
+__global__ void retrieval_ranks_kernel(const float* __restrict__ sim, const int64_t* __restrict__ labels, int n, int m,
+                                       int transpose, int* __restrict__ greater, int* __restrict__ equal) {
+  const int lane = threadIdx.x, i = blockIdx.x;
+  const int cnt = transpose ? n : m;                       // candidates per query
+  const int64_t qs = transpose ? 1 : m, cs = transpose ? m : 1;
+  const int64_t lab = labels ? labels[i] : i;
+  const float d = sim[(int64_t)i * qs + lab * cs];
+  int g = 0, e = 0;
+  for (int j = lane; j < cnt; j += 64) {
+    const float x = sim[(int64_t)i * qs + (int64_t)j * cs];
+    g += x > d; e += x == d;
+  }
+  g = (int)wave_sum((float)g); e = (int)wave_sum((float)e);
+  if (lane == 0) { greater[i] = g; equal[i] = e; }
+}
+
 }  // namespace
+
+extern "C" int xp_sim_matrix(const float* a, const float* b, float* sim, int64_t na, int64_t nb, int64_t d, void* stream) {
+  XP_REQUIRE(a && b && sim && na > 0 && nb > 0 && d > 0, "xp_sim_matrix: bad arguments");
+  dim3 g((unsigned)cdiv(nb, 32), (unsigned)cdiv(na, 32));
+  sgemm_strided_kernel<<<g, 256, 0, (hipStream_t)stream>>>(a, d, 1, b, 1, d, sim, nb, (int)na, (int)nb, (int)d, nullptr);
+  XP_CHECK_LAUNCH("xp_sim_matrix");
+  return XP_OK;
+}
+
+extern "C" int xp_dsl_rerank(float* sim, int64_t n, int64_t m, float theta, int32_t multiply, void* stream) {
+  XP_REQUIRE(sim && n > 0 && m > 0, "xp_dsl_rerank: bad arguments");
+  dsl_rerank_kernel<<<(unsigned)m, 64, 0, (hipStream_t)stream>>>(sim, (int)n, (int)m, theta, multiply);
+  XP_CHECK_LAUNCH("xp_dsl_rerank");
+  return XP_OK;
+}
+
+extern "C" int xp_retrieval_ranks(const float* sim, const int64_t* labels, int64_t n, int64_t m, int32_t transpose,
+                                  int32_t* greater, int32_t* equal, void* stream) {
+  XP_REQUIRE(sim && greater && equal && n > 0 && m > 0 && n < (1 << 24) && m < (1 << 24), "xp_retrieval_ranks: bad arguments");
+  XP_REQUIRE(labels || n == m || (transpose ? m <= n : n <= m), "xp_retrieval_ranks: diagonal labels need a label for every query");
+  const int64_t queries = transpose ? m : n;
+  retrieval_ranks_kernel<<<(unsigned)queries, 64, 0, (hipStream_t)stream>>>(sim, labels, (int)n, (int)m, transpose, greater, equal);
+  XP_CHECK_LAUNCH("xp_retrieval_ranks");
+  return XP_OK;
+}
 
 extern "C" size_t xp_vsc_fc_loss_workspace_bytes(int64_t n, int64_t d) {
   (void)d;

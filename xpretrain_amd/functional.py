@@ -244,7 +244,10 @@ class VisionEmbedFn(torch.autograd.Function):
         if pos_w.shape[0] != 1 + Lp:
             raise ValueError(f"position_embedding has {pos_w.shape[0]} rows but the frame has {Lp} patches (+1)")
         K = 3 * P * P
-        patches = H.im2col(video.reshape(Bv * T, Cc, Hh, Ww).contiguous().float(), P, dtype)
+        if video.dtype == torch.uint8:     # decoded frames: /255, CLIP mean/std and the cast happen inside the gather
+            patches = H.im2col_u8(video.reshape(Bv * T, Cc, Hh, Ww).contiguous(), P, dtype)
+        else:
+            patches = H.im2col(video.reshape(Bv * T, Cc, Hh, Ww).contiguous().float(), P, dtype)
         Wp = WEIGHTS.get(patch_w, dtype).view(D, K)
         x = torch.empty((Bv * S, D), dtype=dtype, device=video.device)
         pos = pos_w.detach().contiguous()

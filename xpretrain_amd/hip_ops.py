@@ -238,6 +238,23 @@ def im2col(video: torch.Tensor, P: int, dtype) -> torch.Tensor:
     return out
 
 
+# CLIP pixel statistics used by every CLIP-ViP transform (datasets/dataloader.py:212-213)
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def im2col_u8(frames: torch.Tensor, P: int, dtype, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """decoded uint8 frames [BT,3,H,W] -> normalised patch matrix [BT*(H/P)*(W/P), 3*P*P] in `dtype`."""
+    if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous():
+        raise TypeError("im2col_u8: frames must be a contiguous uint8 tensor on the GPU (no CPU path)")
+    BT, Cc, H, W = frames.shape
+    assert Cc == 3
+    out = torch.empty((BT * (H // P) * (W // P), 3 * P * P), dtype=dtype, device=frames.device)
+    m, sd = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    L.check(L.lib().xp_im2col_u8(_p(frames), m, sd, _p(out), BT, H, W, P, _DT[dtype], _stream()), "xp_im2col_u8")
+    return out
+
+
 def vip_proxy_rows(class_emb, added_cls, pos, x, B, S, M, D):
     L.check(L.lib().xp_vip_proxy_rows(_p(class_emb), _p(added_cls), _p(pos), _p(x), B, S, M, D, _dt(x), _stream()),
             "xp_vip_proxy_rows")
