@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FC1_PMC_TRAFFIC_BYTES = (94030 * 2 + 226200) * 1024          # profiles/r01l_pmc_*_fc1.csv, see the roofline block
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -232,10 +233,16 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
             "vit_forward_ms": round(vit_fwd_ms, 3),
             "vit_forward_frac_of_bf16_peak": round(f_vis * a.batch / (vit_fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16,NT> fc1 +bias+quick_gelu "
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<NT> fc1 +bias+quick_gelu "
                                                     f"[{rows}x768]x[768x3072]",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(k_ms, 4), "traffic": None},
+                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(k_ms, 4),
+                         # HBM bytes per launch from rocprofv3 PMC passes of tools/fc1_probe.py (separate --pmc runs):
+                         # FETCH_SIZE 94,030 KiB x 2 (gfx950 wide-read correction, confirmed on a 256 MiB xp_cast read in
+                         # the same run) + WRITE_SIZE 226,200 KiB (x 1, same calibration); algorithmic = 33.7 + 231.6 MB.
+                         # Only valid for the shape it was measured on (profiles/r01l_pmc_{fetch,write}_size_fc1.csv).
+                         "traffic": FC1_PMC_TRAFFIC_BYTES if rows == 18848 else None,
+                         "traffic_unit": "bytes/launch", "algorithmic_bytes": (rows * 768 + 3072 * 768 + 2 * rows * 3072) * 2},
         }
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a)

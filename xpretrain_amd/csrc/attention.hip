@@ -406,14 +406,138 @@ __global__ void attn_delta_kernel(AP p) {
   p.ws0[(bb * p.H + h) * p.S + ss] = s;
 }
 
-// dK, dV: workgroup = 64 key rows of one problem; loops over the problem's query tiles.
-__global__ __launch_bounds__(NTHR) void attn_bwd_dkv_kernel(AP p) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + 3 * GR * 4];
-  char* gQ = smem; char* gDO = smem + 4 * TILE;
-  float* gM = reinterpret_cast<float*>(smem + 8 * TILE); float* gLg = gM + GR; float* gDl = gLg + GR;
+// Both backward kernels use the forward's decomposition: 7 waves x 16 OWN rows per workgroup, the OTHER dimension staged
+// in LDS in groups of up to 208 rows by branch-free buffer loads, 64-row steps with a 16-row tail (16x16x16 MFMA), query
+// blocks of one problem 8 workgroup ids apart.  LDS 53-56 KiB: two workgroups per CU.
+
+// cooperative load of rows [row0, row0 + nrows) of TWO row-major operands (own resource / pitch each) into linear swizzled
+// images; rows >= R or >= nrows read as zero.
+__device__ __forceinline__ void stage_rows2(char* gA, char* gB, __amdgpu_buffer_rsrc_t ra, unsigned lda_bytes,
+                                            __amdgpu_buffer_rsrc_t rb, unsigned ldb_bytes, const AP& p, const Prob& pr,
+                                            int row0, int nrows, int tid) {
+  constexpr int NJ = (FG * 8 + FTHR - 1) / FTHR;
+  u32x4 va[NJ], vb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = tid + j * FTHR, row = e >> 3, c = e & 7, r = row0 + row;
+    const bool ok = row < nrows && r < p.R;
+    const unsigned tok = ok ? (unsigned)tok_of(p, pr.n, r) : 0u;
+    va[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? tok * lda_bytes + c * 16 : 0xFFFFFF00u, 0, 0);
+    vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? tok * ldb_bytes + c * 16 : 0xFFFFFF00u, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = tid + j * FTHR, row = e >> 3, c = e & 7;
+    if (row < FG) {
+      *reinterpret_cast<u32x4*>(gA + tile128_off(row, c)) = va[j];
+      *reinterpret_cast<u32x4*>(gB + tile128_off(row, c)) = vb[j];
+    }
+  }
+}
+
+// workgroup id -> (problem, own-row block); false if the id is padding
+__device__ __forceinline__ bool wg_problem(const AP& p, int& prob, int& blk) {
+  const int slot = blockIdx.x >> 3;
+  prob = (slot / p.nq) * 8 + (blockIdx.x & 7);
+  blk = slot % p.nq;
+  return prob < p.nprob;
+}
+
+// ---- dK, dV: the workgroup owns 112 key rows; loops over the problem's query rows (Q, dO, m, log l, delta staged) ----
+struct DkvState { f32x4 dk[4], dv[4]; };
+
+// masked scores for the (own key, staged queries) orientation -- a real call for the same reason as fwd_mask_scores
+__device__ __attribute__((noinline)) S16 dkv_mask_scores(S16 v, int ns, int R, int M, int mode, int n, int rk, int kvalid,
+                                                         int kpad, int qb, int g) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rqq = qb + t * 16 + 4 * g + r;
+      float x = v.s[t][r];
+      if (t < ns) {
+        if (kpad) x = F32_MIN;
+        const bool ok = mode == XP_ATTN_PROXY ? !(rqq < M && rk < M && n != 0) : rk <= rqq;
+        if (!(kvalid && rqq < R && ok)) x = -INFINITY;          // exp(-inf - m - log l) = 0
+      }
+      v.s[t][r] = x;
+    }
+  return v;
+}
+
+template <int NS>
+__device__ __forceinline__ void dkv_step(DkvState& st, const AP& p, const Prob& pr, const char* gQ, const char* gDO,
+                                         const float* gM, const float* gLg, const float* gDl, const bf16x8 (&kf)[2],
+                                         const bf16x8 (&vf)[2], int t0, int qb, int rk, bool kvalid, bool kpad, int wkey0,
+                                         int lane) {
+  const int g = lane >> 4;
+  f32x4 pp[NS], ds[NS];
+  // mask-free path unless a padding mask exists, the causal band crosses this (query step, key wave) pair, or proxy
+  // queries meet proxy keys in a frame n != 0.  Query rows >= R have zero-filled Q/dO rows and (m, log l) = 0, so
+  // their P is finite and multiplies zeros; key lanes >= R only produce their own (discarded) columns.
+  const bool need_mask = p.pad != nullptr ||
+      (p.mode == XP_ATTN_CAUSAL ? qb < wkey0 + 15 : (pr.n != 0 && wkey0 < p.M && qb < p.M));
+  f32x4 sc[NS], dp[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    sc[t] = f32x4{0, 0, 0, 0}; dp[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      sc[t] = mma16(frag_rows(gQ, t0 + t, kk, lane), kf[kk], sc[t]);
+      dp[t] = mma16(frag_rows(gDO, t0 + t, kk, lane), vf[kk], dp[t]);
+    }
+  }
+  if (need_mask) {
+    S16 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v.s[t] = t < NS ? sc[t < NS ? t : 0] : f32x4{0, 0, 0, 0};
+    v = dkv_mask_scores(v, NS, p.R, p.M, p.mode, pr.n, rk, kvalid ? 1 : 0, kpad ? 1 : 0, qb, g);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) sc[t] = v.s[t];
+  }
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    // the lane's 4 query rows are consecutive: one 16-byte LDS read per statistic
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(gM + (t0 + t) * 16 + 4 * g);
+    const f32x4 lg4 = *reinterpret_cast<const f32x4*>(gLg + (t0 + t) * 16 + 4 * g);
+    const f32x4 dl4 = *reinterpret_cast<const f32x4*>(gDl + (t0 + t) * 16 + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pv = __expf((sc[t][r] - m4[r]) - lg4[r]);
+      pp[t][r] = pv;
+      ds[t][r] = pv * (dp[t][r] - dl4[r]);
+    }
+  }
+  const char* sQ = gQ + t0 * 16 * 128;
+  const char* sDO = gDO + t0 * 16 * 128;
+#pragma unroll
+  for (int c = 0; c < NS / 2; ++c) {
+    const bf16x8 pf = pack_p(pp[2 * c], pp[2 * c + 1]), sf = pack_p(ds[2 * c], ds[2 * c + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      st.dv[dt] = mma16(frag_cols(sDO, dt, c, lane), pf, st.dv[dt]);
+      st.dk[dt] = mma16(frag_cols(sQ, dt, c, lane), sf, st.dk[dt]);
+    }
+  }
+  if constexpr (NS & 1) {
+    const s16x4 pf = pack_p4(pp[NS - 1]), sf = pack_p4(ds[NS - 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      st.dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(frag_cols16(sDO, dt, NS - 1, lane), pf, st.dv[dt], 0, 0, 0);
+      st.dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(frag_cols16(sQ, dt, NS - 1, lane), sf, st.dk[dt], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(FTHR, 4) void attn_bwd_dkv_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * FG * 128 + 3 * FG * 4];
+  char* gQ = smem; char* gDO = smem + FG * 128;
+  float* gM = reinterpret_cast<float*>(smem + 2 * FG * 128); float* gLg = gM + FG; float* gDl = gLg + FG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-  const Prob pr(p, blockIdx.y);
-  const int kb = blockIdx.x * TQ;
+  int prob, blk;
+  if (!wg_problem(p, prob, blk)) return;
+  const Prob pr(p, prob);
+  const int kb = blk * FQ;
   const int rk = kb + wave * 16 + i16;            // this lane's key row (column of S)
   const bool kvalid = rk < p.R;
   const int64_t ktok = (int64_t)pr.b * p.S + tok_of(p, pr.n, kvalid ? rk : 0);
@@ -423,105 +547,110 @@ __global__ __launch_bounds__(NTHR) void attn_bwd_dkv_kernel(AP p) {
   load_row_frag(kf, p.qkv + ktok * p.ldqkv + (int64_t)p.H * DH + pr.h * DH, kvalid, g);
   load_row_frag(vf, p.qkv + ktok * p.ldqkv + (int64_t)2 * p.H * DH + pr.h * DH, kvalid, g);
 
-  f32x4 dk[4], dv[4];
+  DkvState st;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+  for (int dt = 0; dt < 4; ++dt) { st.dk[dt] = f32x4{0, 0, 0, 0}; st.dv[dt] = f32x4{0, 0, 0, 0}; }
 
-  const int ntiles = (p.R + 63) / 64;
-  const int qt0 = p.mode == XP_ATTN_CAUSAL ? kb / 64 : 0;     // queries before the first key never see it
-  const bool wave_active = kb + wave * 16 < p.R;
-  for (int qt = qt0; qt < ntiles; ++qt) {
-    const int qb = qt * 64;
-    const int gi = (qt - qt0) & 3;
-    if (gi == 0) {                                      // new query group: ONE load phase for up to 4 tiles
-      if (qt != qt0) __syncthreads();
-      const int nt = ntiles - qt < 4 ? ntiles - qt : 4;
-      load_group(gQ, p.qkv, p.ldqkv, (int64_t)pr.h * DH, p, pr, qb, nt, tid);
-      load_group(gDO, p.dout, p.ldo, (int64_t)pr.h * DH, p, pr, qb, nt, tid);
-      if (tid < GR) {
-        const int r = qb + tid;
-        float mm = 0.f, lg = 0.f, dl = 0.f;
-        if (r < p.R) {
-          const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
-          mm = p.stats[si * 2]; lg = p.stats[si * 2 + 1]; dl = p.ws0[si];
-        }
-        gM[tid] = mm; gLg[tid] = lg; gDl[tid] = dl;
+  const int nsub = (p.R + 15) / 16;
+  const int s0 = p.mode == XP_ATTN_CAUSAL ? (kb / 64) * 4 : 0;     // queries before the first key never see it
+  const bf16_t* qbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
+  const bf16_t* dobase = p.dout + (int64_t)pr.b * p.S * p.ldo + pr.h * DH;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(qbase), 0, (unsigned)(((int64_t)p.S * p.ldqkv - pr.h * DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(dobase), 0, (unsigned)(((int64_t)p.S * p.ldo - pr.h * DH) * 2), 0x00020000);
+  const int wkey0 = kb + wave * 16;
+  const bool wave_active = wkey0 < p.R;
+  for (int g0 = s0; g0 < nsub; g0 += FG / 16) {
+    const int ng = nsub - g0 < FG / 16 ? nsub - g0 : FG / 16;
+    if (g0 != s0) __syncthreads();
+    stage_rows2(gQ, gDO, rq, (unsigned)(p.ldqkv * 2), rdo, (unsigned)(p.ldo * 2), p, pr, g0 * 16, ng * 16, tid);
+    if (tid < FG) {
+      const int r = g0 * 16 + tid;
+      float mm = 0.f, lg = 0.f, dl = 0.f;
+      if (tid < ng * 16 && r < p.R) {
+        const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, r);
+        mm = p.stats[si * 2]; lg = p.stats[si * 2 + 1]; dl = p.ws0[si];
       }
-      __syncthreads();
+      gM[tid] = mm; gLg[tid] = lg; gDl[tid] = dl;
     }
+    __syncthreads();
     if (!wave_active) continue;
-    const char* sQ = gQ + gi * TILE;
-    const char* sDO = gDO + gi * TILE;
-    const float* sM = gM + gi * 64; const float* sLg = gLg + gi * 64; const float* sDl = gDl + gi * 64;
-
-    f32x4 pp[4], ds[4];
-    // mask-free path unless a padding mask exists, the causal band crosses this (query tile, key wave) pair, or proxy
-    // queries meet proxy keys in a frame n != 0.  Query rows >= R have zero-filled Q/dO rows and (m, log l) = 0, so
-    // their P is finite and multiplies zeros; key lanes >= R only produce their own (discarded) columns.
-    const int wkey0 = kb + wave * 16;
-    const bool need_mask = p.pad != nullptr ||
-        (p.mode == XP_ATTN_CAUSAL ? qb < wkey0 + 15 : (pr.n != 0 && wkey0 < p.M && qb < p.M));
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        s = mma16(frag_rows(sQ, t, kk, lane), kf[kk], s);
-        dp = mma16(frag_rows(sDO, t, kk, lane), vf[kk], dp);
-      }
-      // the lane's 4 query rows are consecutive: one 16-byte LDS read per statistic instead of four 4-byte reads
-      const f32x4 m4 = *reinterpret_cast<const f32x4*>(sM + t * 16 + 4 * g);
-      const f32x4 lg4 = *reinterpret_cast<const f32x4*>(sLg + t * 16 + 4 * g);
-      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sDl + t * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rqq = qb + t * 16 + 4 * g + r;
-        float pv;
-        if (need_mask) {
-          pv = 0.f;
-          if (kvalid && rqq < p.R && allowed(p, pr.n, rqq, rk)) {
-            const float sv = kpad ? F32_MIN : s[r];
-            pv = __expf((sv - m4[r]) - lg4[r]);
-          }
-        } else {
-          pv = __expf((s[r] - m4[r]) - lg4[r]);
-        }
-        pp[t][r] = pv;
-        ds[t][r] = pv * (dp[r] - dl4[r]);
-      }
-    }
-    const bf16x8 pf0 = pack_p(pp[0], pp[1]), pf1 = pack_p(pp[2], pp[3]);
-    const bf16x8 sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dv[dt] = mma16(frag_cols(sDO, dt, 0, lane), pf0, dv[dt]);
-      dv[dt] = mma16(frag_cols(sDO, dt, 1, lane), pf1, dv[dt]);
-      dk[dt] = mma16(frag_cols(sQ, dt, 0, lane), sf0, dk[dt]);
-      dk[dt] = mma16(frag_cols(sQ, dt, 1, lane), sf1, dk[dt]);
+    for (int t0 = 0; t0 < ng; t0 += 2) {                // 32 query rows per step: four accumulator sets + S/dP/P/dS of
+      const int qb = (g0 + t0) * 16;                    // 64 rows would not fit 128 registers
+      if (ng - t0 == 1) dkv_step<1>(st, p, pr, gQ, gDO, gM, gLg, gDl, kf, vf, t0, qb, rk, kvalid, kpad, wkey0, lane);
+      else              dkv_step<2>(st, p, pr, gQ, gDO, gM, gLg, gDl, kf, vf, t0, qb, rk, kvalid, kpad, wkey0, lane);
     }
   }
   if (!kvalid) return;
   if (p.mode == XP_ATTN_PROXY && rk < p.M) {
-    float* part = p.ws2 + ((int64_t)blockIdx.y * p.M + rk) * (2 * DH);
+    float* part = p.ws2 + ((int64_t)prob * p.M + rk) * (2 * DH);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, dk[dt]); store4(part + DH + dt * 16 + 4 * g, dv[dt]); }
+    for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, st.dk[dt]); store4(part + DH + dt * 16 + 4 * g, st.dv[dt]); }
     return;
   }
   bf16_t* base = p.dqkv + ktok * p.ldqkv + pr.h * DH;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
-    store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, dk[dt]);
-    store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, dv[dt]);
+    store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, st.dk[dt]);
+    store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, st.dv[dt]);
   }
 }
 
-// dQ: workgroup = 64 query rows; loops over key tiles (transposed orientation, per-lane query scalars).
-__global__ __launch_bounds__(NTHR) void attn_bwd_dq_kernel(AP p) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + GR];
-  char* gK = smem; char* gV = smem + 4 * TILE; unsigned char* gPad = reinterpret_cast<unsigned char*>(smem + 8 * TILE);
+// ---- dQ: the workgroup owns 112 query rows; loops over the key rows (K, V staged; transposed orientation) -----------
+template <int NS>
+__device__ __forceinline__ void dq_step(f32x4 (&dq)[4], const AP& p, const Prob& pr, const char* gK, const char* gV,
+                                        const unsigned char* gPad, const bf16x8 (&qf)[2], const bf16x8 (&dof)[2], float mq,
+                                        float lgq, float dlq, int t0, int kb, int rq, bool qvalid, int wrow0, int lane) {
+  const int g = lane >> 4;
+  f32x4 ds[NS];
+  const bool need_mask = kb + NS * 16 > p.R || p.pad != nullptr ||
+      (p.mode == XP_ATTN_CAUSAL ? kb + NS * 16 - 1 > wrow0 : (pr.n != 0 && kb < p.M && wrow0 < p.M));
+  f32x4 sc[NS], dp[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    sc[t] = f32x4{0, 0, 0, 0}; dp[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      sc[t] = mma16(frag_rows(gK, t0 + t, kk, lane), qf[kk], sc[t]);
+      dp[t] = mma16(frag_rows(gV, t0 + t, kk, lane), dof[kk], dp[t]);
+    }
+  }
+  if (need_mask) {
+    S16 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v.s[t] = t < NS ? sc[t < NS ? t : 0] : f32x4{0, 0, 0, 0};
+    v = fwd_mask_scores(v, NS, gPad + t0 * 16, p.R, p.M, p.mode, pr.n, rq, qvalid ? 1 : 0, kb, g);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) sc[t] = v.s[t];
+  }
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[t][r] = __expf((sc[t][r] - mq) - lgq) * (dp[t][r] - dlq);
+  const char* sK = gK + t0 * 16 * 128;
+#pragma unroll
+  for (int c = 0; c < NS / 2; ++c) {
+    const bf16x8 sf = pack_p(ds[2 * c], ds[2 * c + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = mma16(frag_cols(sK, dt, c, lane), sf, dq[dt]);
+  }
+  if constexpr (NS & 1) {
+    const s16x4 sf = pack_p4(ds[NS - 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(frag_cols16(sK, dt, NS - 1, lane), sf, dq[dt], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(FTHR, 4) void attn_bwd_dq_kernel(AP p) {
+  __shared__ __attribute__((aligned(16))) char smem[F_LDS];
+  char* gK = smem; char* gV = smem + FG * 128; unsigned char* gPad = reinterpret_cast<unsigned char*>(smem + 2 * FG * 128);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-  const Prob pr(p, blockIdx.y);
-  const int qb = blockIdx.x * TQ;
+  int prob, blk;
+  if (!wg_problem(p, prob, blk)) return;
+  const Prob pr(p, prob);
+  const int qb = blk * FQ;
   const int rq = qb + wave * 16 + i16;
   const bool qvalid = rq < p.R;
   const int64_t qtok = (int64_t)pr.b * p.S + tok_of(p, pr.n, qvalid ? rq : 0);
@@ -538,62 +667,32 @@ __global__ __launch_bounds__(NTHR) void attn_bwd_dq_kernel(AP p) {
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
 
-  int ntiles = (p.R + 63) / 64;
-  if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + TQ - 1) / 64 + 1; ntiles = ntiles < lim ? ntiles : lim; }
-  const int64_t kcol = (int64_t)p.H * DH + pr.h * DH, vcol = (int64_t)2 * p.H * DH + pr.h * DH;
-  const bool wave_active = qb + wave * 16 < p.R;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int kb = kt * 64;
-    if ((kt & 3) == 0) {
-      if (kt) __syncthreads();
-      const int nt = ntiles - kt < 4 ? ntiles - kt : 4;
-      load_group(gK, p.qkv, p.ldqkv, kcol, p, pr, kb, nt, tid);
-      load_group(gV, p.qkv, p.ldqkv, vcol, p, pr, kb, nt, tid);
-      if (tid < GR) { const int r = kb + tid; gPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0; }
-      __syncthreads();
-    }
+  int nsub = (p.R + 15) / 16;
+  if (p.mode == XP_ATTN_CAUSAL) { const int lim = (qb + FQ - 1) / 16 + 1; nsub = nsub < lim ? nsub : lim; }
+  const bf16_t* kbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + (int64_t)p.H * DH + pr.h * DH;
+  const unsigned ld_bytes = (unsigned)(p.ldqkv * 2);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (unsigned)((int64_t)p.S * p.ldqkv * 2 - ((int64_t)p.H * DH + pr.h * DH) * 2), 0x00020000);
+  const unsigned voff_v = (unsigned)(p.H * DH * 2);
+  const int wrow0 = qb + wave * 16;
+  const bool wave_active = wrow0 < p.R;
+  for (int g0 = 0; g0 < nsub; g0 += FG / 16) {
+    const int ng = nsub - g0 < FG / 16 ? nsub - g0 : FG / 16;
+    if (g0) __syncthreads();
+    fwd_load_kv(gK, gV, rs, ld_bytes, voff_v, p, pr, g0 * 16, ng * 16, tid);
+    if (tid < FG) { const int r = g0 * 16 + tid; gPad[tid] = (p.pad && r < p.R) ? (p.pad[(int64_t)pr.b * p.S + r] == 0) : 0; }
+    __syncthreads();
     if (!wave_active) continue;
-    const char* sK = gK + (kt & 3) * TILE;
-    const char* sV = gV + (kt & 3) * TILE;
-    const unsigned char* sPad = gPad + (kt & 3) * 64;
-    f32x4 ds[4];
-    const int wrow0 = qb + wave * 16;
-    const bool need_mask = kb + 64 > p.R || p.pad != nullptr ||
-        (p.mode == XP_ATTN_CAUSAL ? kb + 63 > wrow0 : (pr.n != 0 && kb < p.M && wrow0 < p.M));
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        s = mma16(frag_rows(sK, t, kk, lane), qf[kk], s);
-        dp = mma16(frag_rows(sV, t, kk, lane), dof[kk], dp);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kl = t * 16 + 4 * g + r, rk = kb + kl;
-        float pv;
-        if (need_mask) {
-          pv = 0.f;
-          if (qvalid && rk < p.R && allowed(p, pr.n, rq, rk)) {
-            const float sv = sPad[kl] ? F32_MIN : s[r];
-            pv = __expf((sv - mq) - lgq);
-          }
-        } else {
-          pv = __expf((s[r] - mq) - lgq);
-        }
-        ds[t][r] = pv * (dp[r] - dlq);
-      }
-    }
-    const bf16x8 sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dq[dt] = mma16(frag_cols(sK, dt, 0, lane), sf0, dq[dt]);
-      dq[dt] = mma16(frag_cols(sK, dt, 1, lane), sf1, dq[dt]);
+    for (int t0 = 0; t0 < ng; t0 += 4) {
+      const int ns = ng - t0 < 4 ? ng - t0 : 4;
+      const int kb = (g0 + t0) * 16;
+      if (ns == 1) dq_step<1>(dq, p, pr, gK, gV, gPad, qf, dof, mq, lgq, dlq, t0, kb, rq, qvalid, wrow0, lane);
+      else         dq_step<4>(dq, p, pr, gK, gV, gPad, qf, dof, mq, lgq, dlq, t0, kb, rq, qvalid, wrow0, lane);
     }
   }
   if (!qvalid) return;
   if (p.mode == XP_ATTN_PROXY && rq < p.M) {
-    float* part = p.ws1 + ((int64_t)blockIdx.y * p.M + rq) * DH;
+    float* part = p.ws1 + ((int64_t)prob * p.M + rq) * DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4(part + dt * 16 + 4 * g, dq[dt]);
     return;
@@ -693,10 +792,11 @@ extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, cons
   hipStream_t st = (hipStream_t)stream;
   attn_delta_kernel<<<(unsigned)cdiv(B * S * H, 256), 256, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(delta)");
-  dim3 grid((unsigned)cdiv(p.R, TQ), (unsigned)P);
-  attn_bwd_dkv_kernel<<<grid, NTHR, 0, st>>>(p);
+  p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)P;
+  const unsigned grid = (unsigned)(cdiv(p.nprob, 8) * 8 * p.nq);
+  attn_bwd_dkv_kernel<<<grid, FTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
-  attn_bwd_dq_kernel<<<grid, NTHR, 0, st>>>(p);
+  attn_bwd_dq_kernel<<<grid, FTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
   if (mode == XP_ATTN_PROXY) {
     attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
