@@ -89,8 +89,8 @@ int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dt
               int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Deferred form: first level only.  partials[r*cols + n] = sum over the r-th chunk of rows of X[.][n];
- * xp_colsum_partial_rows(rows) chunks.  Finish with xp_reduce_rows_batch. */
-int64_t xp_colsum_partial_rows(int64_t rows);
+ * xp_colsum_partial_rows(rows, cols) chunks.  Finish with xp_reduce_rows_batch. */
+int64_t xp_colsum_partial_rows(int64_t rows, int64_t cols);
 int xp_colsum_partials(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* partials,
                        size_t partials_bytes, void* stream);
 

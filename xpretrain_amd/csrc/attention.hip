@@ -386,26 +386,6 @@ __global__ void attn_fwd_merge_kernel(AP p) {
 }
 
 // ============================================================================================ backward
-// delta[b,h,s] = sum_d dO * O      (one thread per (token, head))
-__global__ void attn_delta_kernel(AP p) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)p.B * p.S * p.H;
-  if (idx >= total) return;
-  const int h = (int)(idx % p.H);
-  const int64_t tok = idx / p.H;
-  const bf16_t* a = p.out + tok * p.ldo + h * DH;
-  const bf16_t* b = p.dout + tok * p.ldo + h * DH;
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c * 8), y = *reinterpret_cast<const bf16x8*>(b + c * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
-  }
-  const int64_t bb = tok / p.S, ss = tok % p.S;
-  p.ws0[(bb * p.H + h) * p.S + ss] = s;
-}
-
 // Both backward kernels use the forward's decomposition: 7 waves x 16 OWN rows per workgroup, the OTHER dimension staged
 // in LDS in groups of up to 208 rows by branch-free buffer loads, 64-row steps with a 16-row tail (16x16x16 MFMA), query
 // blocks of one problem 8 workgroup ids apart.  LDS 53-56 KiB: two workgroups per CU.
@@ -658,10 +638,21 @@ __global__ __launch_bounds__(FTHR, 4) void attn_bwd_dq_kernel(AP p) {
   bf16x8 qf[2], dof[2];
   load_row_frag(qf, p.qkv + qtok * p.ldqkv + pr.h * DH, qvalid, g);
   load_row_frag(dof, p.dout + qtok * p.ldo + pr.h * DH, qvalid, g);
-  float mq = 0.f, lgq = 0.f, dlq = 0.f;
+  // delta = sum_d dO * O of the own row, from the fragments already in registers (each of the 4 lanes of a row holds 16
+  // of the 64 d); published in ws0 for the dK/dV kernel, which runs after this one
+  bf16x8 of[2];
+  load_row_frag(of, p.out + qtok * p.ldo + pr.h * DH, qvalid, g);
+  float dlq = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dlq += (float)dof[kk][e] * (float)of[kk][e];
+  dlq = group_sum(dlq);
+  float mq = 0.f, lgq = 0.f;
   if (qvalid) {
     const int64_t si = ((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, rq);
-    mq = p.stats[si * 2]; lgq = p.stats[si * 2 + 1]; dlq = p.ws0[si];
+    mq = p.stats[si * 2]; lgq = p.stats[si * 2 + 1];
+    if (g == 0 && (p.mode != XP_ATTN_PROXY || rq >= p.M || pr.n == 0)) p.ws0[si] = dlq;   // proxy rows: frame 0 writes
   }
   f32x4 dq[4];
 #pragma unroll
@@ -790,14 +781,12 @@ extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, cons
   const int64_t P = B * H * N;
   p.ws0 = (float*)workspace; p.ws1 = p.ws0 + B * H * S; p.ws2 = p.ws1 + P * M * DH;
   hipStream_t st = (hipStream_t)stream;
-  attn_delta_kernel<<<(unsigned)cdiv(B * S * H, 256), 256, 0, st>>>(p);
-  XP_CHECK_LAUNCH("xp_attn_bwd(delta)");
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)P;
   const unsigned grid = (unsigned)(cdiv(p.nprob, 8) * 8 * p.nq);
+  attn_bwd_dq_kernel<<<grid, FTHR, 0, st>>>(p);          // also computes delta = rowsum(dO * O) into ws0
+  XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
   attn_bwd_dkv_kernel<<<grid, FTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
-  attn_bwd_dq_kernel<<<grid, FTHR, 0, st>>>(p);
-  XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
   if (mode == XP_ATTN_PROXY) {
     attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
     XP_CHECK_LAUNCH("xp_attn_bwd(proxy reduce)");

@@ -413,10 +413,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
 // Column sums (bias gradients): block = 4 waves; wave w sums rows r0+w, r0+w+4, ... of a CS_ROWS-row chunk for 256
 // columns (4 per lane, 8/16-byte loads, 512 B contiguous per wave instruction), 4-deep independent accumulators;
 // LDS combine of the 4 waves; one partial row per chunk -> splitk_reduce.  Grid: (cols/256, rows/CS_ROWS).
-constexpr int CS_ROWS = 32;
+// rows per chunk: narrow matrices need many chunks to fill the chip, wide ones can take longer chunks (fewer partial rows
+// for the second level): aim at >= ~2048 workgroups, 32..128 rows each
+static inline int cs_rows(int64_t rows, int64_t cols) {
+  const int64_t per = rows * cdiv(cols, 256) / 2048;
+  return per >= 128 ? 128 : (per >= 64 ? 64 : 32);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, int CS_ROWS) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
@@ -627,17 +632,17 @@ extern "C" int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32
   return XP_OK;
 }
 
-extern "C" int64_t xp_colsum_partial_rows(int64_t rows) { return cdiv(rows, CS_ROWS); }
+extern "C" int64_t xp_colsum_partial_rows(int64_t rows, int64_t cols) { return cdiv(rows, cs_rows(rows, cols)); }
 
 extern "C" int xp_colsum_partials(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* partials,
                                   size_t partials_bytes, void* stream) {
   XP_REQUIRE(X && partials && rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0, "xp_colsum_partials: bad arguments");
-  const int chunks = (int)cdiv(rows, CS_ROWS);
+  const int csr = cs_rows(rows, cols), chunks = (int)cdiv(rows, csr);
   XP_REQUIRE(partials_bytes >= (size_t)chunks * cols * sizeof(float), "xp_colsum_partials: partials buffer too small");
   dim3 grid((unsigned)cdiv(cols, 256), chunks);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, rows, cols, ldx, partials);
-  else if (dtype == XP_F32) colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, rows, cols, ldx, partials);
+  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, rows, cols, ldx, partials, csr);
+  else if (dtype == XP_F32) colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, rows, cols, ldx, partials, csr);
   else XP_REQUIRE(false, "xp_colsum_partials: bad dtype %d", dtype);
   XP_CHECK_LAUNCH("xp_colsum_partials");
   return XP_OK;
@@ -678,19 +683,19 @@ extern "C" int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, voi
 }
 
 extern "C" size_t xp_colsum_workspace_bytes(int64_t rows, int64_t cols) {
-  return (size_t)((cdiv(rows, CS_ROWS) + 32) * cols * sizeof(float));
+  return (size_t)((cdiv(rows, 32) + 32) * cols * sizeof(float));
 }
 
 extern "C" int xp_colsum(const void* X, int64_t rows, int64_t cols, int64_t ldx, int32_t dtype, float* out,
                          int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   XP_REQUIRE(X && out && rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0, "xp_colsum: bad arguments");
   XP_REQUIRE(workspace && workspace_bytes >= xp_colsum_workspace_bytes(rows, cols), "xp_colsum: workspace too small");
-  const int chunks = (int)cdiv(rows, CS_ROWS);
+  const int csr = cs_rows(rows, cols), chunks = (int)cdiv(rows, csr);
   dim3 grid((unsigned)cdiv(cols, 256), chunks);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, rows, cols, ldx, part);
-  else                  colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, rows, cols, ldx, part);
+  if (dtype == XP_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, rows, cols, ldx, part, csr);
+  else                  colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, rows, cols, ldx, part, csr);
   XP_CHECK_LAUNCH("xp_colsum(partial)");
   // two-level deterministic reduce of the chunk partials (chunks -> <=32 -> 1): no thread walks hundreds of rows
   const int lvl = (int)cdiv(chunks, 32), n2 = (int)cdiv(chunks, lvl);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce2_kernel(const float* __re
   }
 }
 
-inline int bwd_blocks(int64_t rows) { int64_t b = cdiv(rows, WAVES * 4); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+inline int bwd_blocks(int64_t rows) { int64_t b = cdiv(rows, WAVES * 4); return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
 
 }  // namespace
 

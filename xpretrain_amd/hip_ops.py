@@ -165,7 +165,7 @@ def colsum_deferred(X: torch.Tensor, rows: int, cols: int, defer: DeferredReduce
     """Bias gradient whose final reduction is finished by ``defer.flush()``."""
     _chk(X, "X")
     out = torch.empty(cols, dtype=torch.float32, device=X.device)
-    chunks = L.lib().xp_colsum_partial_rows(rows)
+    chunks = L.lib().xp_colsum_partial_rows(rows, cols)
     part = defer.slot(chunks * cols * 4)
     L.check(L.lib().xp_colsum_partials(_p(X), rows, cols, ldx or cols, _dt(X), _p(part), part.numel(), _stream()),
             "xp_colsum_partials")
