@@ -1,0 +1,62 @@
+"""GPU: the RCCL code path of distributed.py on ONE GPU -- a 1-rank `nccl` process group with the collectives forced on:
+packed feature all-gather (+ its collective-free backward and the verify switch), bucketed asynchronous gradient
+all-reduce driven by autograd hooks, parameter broadcast, then clip + AdamW reading the flat bucket views.  The result
+must equal the plain single-process step.  (Multi-rank semantics are covered on gloo by tests/test_distributed_cpu.py.)"""
+import os
+
+import pytest
+import torch
+
+from oracle import clipvip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(model, opt, reducer, D, batch):
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    video, ids, mask = batch
+    out = model(video, ids, mask)
+    vis, txt = D.gather_features(out["vis_features"], out["text_features"], verify_identical=True)
+    loss = NCELearnableTempLoss()(vis, txt, model.clipmodel.logit_scale)
+    loss.backward()
+    reducer.synchronize()
+    norm = opt.clip_and_step(1.0)
+    reducer.zero_grad()
+    return loss.detach().clone(), norm.detach().clone()
+
+
+def test_one_rank_nccl_group_matches_plain_step():
+    import torch.distributed as dist
+    from xpretrain_amd import distributed as D
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import AdamW
+    from tests.test_model_gpu import _Args
+    cfgd = O.hf_config_dict(128, 2, 2, 256, 16, 32, 128, 2, 2, 256, 120, 16, 64)
+    video, ids, mask = O.synthetic_inputs(4, 2, 32, 8, vocab=120)
+    batch = (video.cuda(), ids.cuda(), mask.cuda())
+
+    def run(distributed):
+        torch.manual_seed(5)
+        model = VidCLIP(_Args(cfgd, 2)).cuda().train()
+        D.broadcast_parameters(model)
+        reducer = D.GradBucketReducer(model.parameters(), bucket_mb=0.25, average=True)     # several buckets
+        assert reducer._active == distributed
+        opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+        res = [_step(model, opt, reducer, D, batch) for _ in range(3)]
+        reducer.remove()
+        return res, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    plain, sd0 = run(False)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", world_size=1, rank=0)
+    try:
+        D.FORCE_COLLECTIVES = True
+        forced, sd1 = run(True)
+    finally:
+        D.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
+    for (l0, n0), (l1, n1) in zip(plain, forced):
+        assert abs(l0.item() - l1.item()) <= 1e-5 * max(1.0, abs(l0.item()))
+        assert abs(n0.item() - n1.item()) <= 1e-4 * max(1.0, abs(n0.item()))
+    for k in sd0:
+        assert torch.allclose(sd0[k].float(), sd1[k].float(), rtol=1e-5, atol=1e-6), k

@@ -73,15 +73,23 @@ class _AllGatherRows(torch.autograd.Function):
         return g[r * ctx.n:(r + 1) * ctx.n], None
 
 
+# Test hook: run the collectives even in a 1-rank group (exercises the RCCL code path on a single GPU).
+FORCE_COLLECTIVES = False
+
+
+def _single() -> bool:
+    return world_size() == 1 and not (FORCE_COLLECTIVES and dist.is_initialized())
+
+
 def allgather(x: torch.Tensor, verify_identical: bool = False) -> torch.Tensor:
-    if world_size() == 1:
+    if _single():
         return x
     return _AllGatherRows.apply(x, verify_identical)
 
 
 def gather_features(vis: torch.Tensor, txt: torch.Tensor, verify_identical: bool = False):
     """(vis[B,d], txt[B,d]) -> (vis[W*B,d], txt[W*B,d]) with ONE collective."""
-    if world_size() == 1:
+    if _single():
         return vis, txt
     B = vis.shape[0]
     packed = torch.stack([vis, txt], dim=1)                       # [B,2,d]: rows stay rank-major after the gather
@@ -105,7 +113,7 @@ class GradBucketReducer:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.buckets = []
         self._bucket_of = {}
-        self._active = world_size() > 1
+        self._active = not _single()
         cap = int(bucket_mb * (1 << 20)) // 4
         cur, cur_n = [], 0
         for p in reversed(self.params):        # gradients become ready roughly in reverse parameter order
@@ -184,7 +192,7 @@ class GradBucketReducer:
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
-    if world_size() == 1:
+    if _single():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
