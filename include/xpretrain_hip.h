@@ -70,6 +70,12 @@ typedef struct XpGemmDesc {
   const void* resid; int64_t ldr;       /* dtype = in_dtype                                        */
   void* aux; int64_t ldaux;             /* dtype = out_dtype                                       */
   const float* tab1; const float* tab2; int64_t tab_L;
+  /* optional: column sums of the FINISHED outputs (fp32, before rounding), one partial row per 128 output rows:
+   * colsum_partials[r*N + n], r < xp_gemm_colsum_rows(desc).  This is the bias gradient of the Linear whose output
+   * gradient this GEMM produces (autograd computes it as grad.sum(0), CLIP_ViP.py:383-396) without re-reading it.
+   * Only where xp_gemm_colsum_rows() > 0 (large bf16 problems, EPI_NONE / EPI_GELU_BWD); finish with
+   * xp_reduce_rows_batch. */
+  float* colsum_partials;
 } XpGemmDesc;
 
 int xp_gemm(const XpGemmDesc* desc, void* stream);
@@ -79,6 +85,9 @@ int xp_gemm(const XpGemmDesc* desc, void* stream);
  * of workgroups of the kernel family xp_gemm will pick for `desc` (desc->split_k and the data pointers are
  * ignored).  The value is always accepted by xp_gemm (whole k-steps per slab, no empty slab); 1 = no split. */
 int32_t xp_gemm_auto_split(const XpGemmDesc* desc);
+/* number of partial rows xp_gemm writes to desc->colsum_partials, or 0 if the fused column sums are not available
+ * for this problem (desc->colsum_partials itself is ignored here) */
+int64_t xp_gemm_colsum_rows(const XpGemmDesc* desc);
 
 /* out[i] (+)= sum_z slabs[z*n + i], fp32; accumulate != 0 adds into out (gradient accumulation). */
 int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);

@@ -38,6 +38,7 @@ class XpGemmDesc(C.Structure):
         ("resid", vp), ("ldr", i64),
         ("aux", vp), ("ldaux", i64),
         ("tab1", vp), ("tab2", vp), ("tab_L", i64),
+        ("colsum_partials", vp),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "xp_last_error": (C.c_char_p, []),
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
     "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
+    "xp_gemm_colsum_rows": (i64, [C.POINTER(XpGemmDesc)]),
     "xp_colsum_partial_rows": (i64, [i64, i64]),
     "xp_colsum_partials": (i32, [vp, i64, i64, i64, i32, vp, sz, vp]),
     "xp_reduce_rows_batch_workspace_bytes": (sz, [C.POINTER(XpReduceSeg), i32]),

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
   if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
-  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c) {
+  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c, auto) {      // (no fused column sums in this family)
     constexpr int EPI = decltype(epi_c)::value;
     constexpr bool F32 = decltype(f32_c)::value;
     constexpr int RPP = NWV * 4, NP = 128 / RPP;    // 16 lanes per row, RPP rows per pass
@@ -571,13 +571,11 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
   kp.dbg = g_gemm_trace;
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
-  {
-    // fast epilogue (gemm_common.h): 32-bit buffer offsets must not wrap for any row of the last tile
-    const int64_t osz = kp.out_f32 ? 4 : esz, lim = (int64_t)EPI_OOB - 64;
-    const int64_t rows = d->M + 256;
-    kp.fast_epi = (kp.wide && d->c_grp == 0 && !getenv("XPRETRAIN_GEMM_SLOW_EPI") && rows * d->ldc * osz < lim &&
-                   (!d->resid || rows * d->ldr * esz < lim) && (!d->aux || rows * d->ldaux * osz < lim)) ? 1 : 0;
-  }
+  kp.fast_epi = (kp.wide && xp_gemm_fast_epi_ok(d)) ? 1 : 0;
+  kp.colsum = d->colsum_partials;
+  if (d->colsum_partials)
+    XP_REQUIRE(xp_gemm_colsum_rows(d) > 0, "xp_gemm: fused column sums are not available for this problem "
+               "(xp_gemm_colsum_rows() == 0): use xp_colsum / xp_colsum_partials");
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
   {
     static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 4;
@@ -599,6 +597,23 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   else                        launch<float>(d, kp, grid, st);
   XP_CHECK_LAUNCH("xp_gemm");
   return XP_OK;
+}
+
+// fast epilogue (gemm_common.h): identity row map, 32-bit buffer offsets that cannot wrap for any row of the last tile
+bool xp_gemm_fast_epi_ok(const XpGemmDesc* d) {
+  if (getenv("XPRETRAIN_GEMM_SLOW_EPI")) return false;
+  const int64_t esz = d->in_dtype == XP_BF16 ? 2 : 4, osz = d->out_dtype == XP_F32 ? 4 : esz, lim = (int64_t)EPI_OOB - 64;
+  const int64_t rows = d->M + 256;
+  const bool wide = d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0);
+  return wide && d->c_grp == 0 && rows * d->ldc * osz < lim && (!d->resid || rows * d->ldr * esz < lim) &&
+         (!d->aux || rows * d->ldaux * osz < lim);
+}
+
+extern "C" int64_t xp_gemm_colsum_rows(const XpGemmDesc* d) {
+  if (!d || d->split_k > 1 || d->in_dtype != XP_BF16 || d->out_dtype != XP_BF16) return 0;
+  if (d->epilogue != XP_EPI_NONE && d->epilogue != XP_EPI_GELU_BWD) return 0;
+  if (!xp_gemm_fast_epi_ok(d) || !xp_gemm256_wanted(d, 1) || cdiv(d->K, 64) < 2) return 0;
+  return 2 * cdiv(d->M, 256);
 }
 
 // split s0 rounded to one xp_gemm accepts (whole k-steps per slab, no empty slab)

@@ -237,9 +237,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
-  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c) {
+  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c, auto cs_c) {
     constexpr int EPI = decltype(epi_c)::value;
     constexpr bool F32 = decltype(f32_c)::value;
+    constexpr bool COLSUM = decltype(cs_c)::value;
+    f32x8 cs = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int c = lane & 7, r8 = lane >> 3;           // 8 columns per lane: 8 lanes per row, 8 rows per pass
     const FastEpi<T, EPI, F32> fe(p, F32 ? (void*)Cf : (void*)Ct, n0 + wn * CW + c * 8);
     const unsigned mrow = (unsigned)(m0 + wm * (MT * 16)) + r8;
@@ -265,8 +267,26 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
         v[pass].hi = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c + 1) ^ (row & 7)) << 4));
       }
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) fe.finish(v[pass], pre[q & 1][pass], mrow + q * 32 + pass * 8);
+      for (int pass = 0; pass < 4; ++pass) {
+        const f32x8 o = fe.finish(v[pass], pre[q & 1][pass], mrow + q * 32 + pass * 8);
+        if constexpr (COLSUM) {
+          if (mrow + q * 32 + pass * 8 < (unsigned)p.M) { cs.lo += o.lo; cs.hi += o.hi; }     // rows >= M are not outputs
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (COLSUM) {
+      // the 8 lanes r8 = 0..7 of a column octet hold different rows: butterfly over lane bits 3..5, then lane r8 == 0
+      // writes this wave's 128-row column sums (one partial row per (tile row, wm))
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs.lo[e] += __shfl_xor(cs.lo[e], o, 64); cs.hi[e] += __shfl_xor(cs.hi[e], o, 64); }
+      const int64_t n = n0 + wn * CW + c * 8;
+      if (r8 == 0 && n < p.N) {
+        float* dst = p.colsum + ((int64_t)tm * 2 + wm) * p.N + n;
+        store4(dst, cs.lo); store4(dst + 4, cs.hi);
+      }
     }
   });
   if (fast) {

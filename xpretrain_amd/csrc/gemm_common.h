@@ -27,6 +27,7 @@ struct KParams {
   int xcd_remap;             // 1: consecutive tile ids -> same XCD (default); 0: hardware round-robin (A/B switch)
   int wide;                  // 1: N, ldc, ldr, ldaux all multiples of 8 -> 8 columns per lane, 16-byte bf16 stores
   int fast_epi;              // 1: wide, identity cmap, C / resid / aux each < 4 GiB -> branch-free buffer-addressed epilogue
+  float* colsum;             // optional [2 * tiles_m][N] column sums of the finished outputs per 128-row wave block (256 family)
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
 
@@ -176,7 +177,7 @@ struct FastEpi {
   __device__ __forceinline__ unsigned off_c(unsigned m) const { return ok ? m * ld_c + col_c : EPI_OOB; }
   __device__ __forceinline__ unsigned off_x(unsigned m) const { return ok ? m * ld_x + col_x : EPI_OOB; }
   __device__ __forceinline__ Raw8<T> load_pre(unsigned m) const { return bload8<T>(rx, off_x(m)); }
-  __device__ __forceinline__ void finish(f32x8 v, const Raw8<T>& pre, unsigned m) const {
+  __device__ __forceinline__ f32x8 finish(f32x8 v, const Raw8<T>& pre, unsigned m) const {
     if constexpr (Tr::bias) { v.lo += bias.lo; v.hi += bias.hi; }
     if constexpr (Tr::scale) { v.lo *= cs_lo; v.hi *= cs_hi; }
     if constexpr (EPI == XP_EPI_BIAS_GELU) {
@@ -192,26 +193,34 @@ struct FastEpi {
       for (int e = 0; e < 4; ++e) { v.lo[e] *= quick_gelu_grad_f(r.lo[e]); v.hi[e] *= quick_gelu_grad_f(r.hi[e]); }
     }
     bstore8<T, F32>(rc, off_c(m), v);
+    return v;
   }
 };
 
-// Calls f(integral_constant<int, EPI>, bool_constant<F32>) for the (epilogue, output type) pairs the fast path
-// specialises; returns false for any other pair (the caller then runs the generic epilogue).
+// Calls f(integral_constant<int, EPI>, bool_constant<F32>, bool_constant<COLSUM>) for the (epilogue, output type) pairs the
+// fast path specialises; returns false for any other pair (the caller then runs the generic epilogue).  COLSUM (column
+// sums of the finished outputs, i.e. the bias gradient of the layer that produced this GEMM's input gradient) exists for
+// the two epilogues the backward uses it with; the host rejects every other combination.
 template <typename F>
 __device__ __forceinline__ bool fast_epi_dispatch(const KParams& p, F&& f) {
   using std::integral_constant; using std::bool_constant;
   if (!p.fast_epi) return false;
+  if (p.colsum) {
+    if (p.epilogue == XP_EPI_GELU_BWD) f(integral_constant<int, XP_EPI_GELU_BWD>{}, bool_constant<false>{}, bool_constant<true>{});
+    else                               f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<false>{}, bool_constant<true>{});
+    return true;
+  }
   if (p.out_f32) {
-    if (p.epilogue == XP_EPI_NONE) { f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<true>{}); return true; }
+    if (p.epilogue == XP_EPI_NONE) { f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<true>{}, bool_constant<false>{}); return true; }
     return false;
   }
   switch (p.epilogue) {
-    case XP_EPI_NONE:        f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<false>{}); return true;
-    case XP_EPI_BIAS:        f(integral_constant<int, XP_EPI_BIAS>{}, bool_constant<false>{}); return true;
-    case XP_EPI_BIAS_QSCALE: f(integral_constant<int, XP_EPI_BIAS_QSCALE>{}, bool_constant<false>{}); return true;
-    case XP_EPI_BIAS_GELU:   f(integral_constant<int, XP_EPI_BIAS_GELU>{}, bool_constant<false>{}); return true;
-    case XP_EPI_BIAS_RESID:  f(integral_constant<int, XP_EPI_BIAS_RESID>{}, bool_constant<false>{}); return true;
-    case XP_EPI_GELU_BWD:    f(integral_constant<int, XP_EPI_GELU_BWD>{}, bool_constant<false>{}); return true;
+    case XP_EPI_NONE:        f(integral_constant<int, XP_EPI_NONE>{}, bool_constant<false>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS:        f(integral_constant<int, XP_EPI_BIAS>{}, bool_constant<false>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS_QSCALE: f(integral_constant<int, XP_EPI_BIAS_QSCALE>{}, bool_constant<false>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS_GELU:   f(integral_constant<int, XP_EPI_BIAS_GELU>{}, bool_constant<false>{}, bool_constant<false>{}); return true;
+    case XP_EPI_BIAS_RESID:  f(integral_constant<int, XP_EPI_BIAS_RESID>{}, bool_constant<false>{}, bool_constant<false>{}); return true;
+    case XP_EPI_GELU_BWD:    f(integral_constant<int, XP_EPI_GELU_BWD>{}, bool_constant<false>{}, bool_constant<false>{}); return true;
     default: return false;
   }
 }
@@ -246,3 +255,4 @@ __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int gr
 bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st);
 bool xp_gemm256_legal(const XpGemmDesc* d);
 bool xp_gemm256_wanted(const XpGemmDesc* d, int split);
+bool xp_gemm_fast_epi_ok(const XpGemmDesc* d);

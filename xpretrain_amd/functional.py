@@ -203,12 +203,12 @@ class EncoderLayerFn(torch.autograd.Function):
         dx3 = dx3.contiguous()
         defer = H.DeferredReduce(x.device)       # the 4 bias + 4 LayerNorm-parameter reductions finish in 2 launches
         # ---- MLP: x3 = x2 + fc2(quick_gelu(fc1(LN2(x2))))
-        dpre = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre)
+        # fc1's bias gradient = column sums of dpre: taken from the epilogue of the GEMM that produces dpre
+        dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre, colsum_defer=defer)
         dw2 = _wgrad(dx3, act, rows, D, Dff)
         db2 = H.colsum_deferred(dx3, rows, D, defer)
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
         dw1 = _wgrad(dpre, h2, rows, Dff, D)
-        db1 = H.colsum_deferred(dpre, rows, Dff, defer)
         dx2, dln2_w, dln2_b = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer)
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)

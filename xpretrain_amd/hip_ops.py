@@ -59,8 +59,12 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
          a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
          scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
-         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None) -> torch.Tensor:
-    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc."""
+         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None):
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc.
+
+    ``colsum_defer`` (a DeferredReduce): also return the column sums of C (a bias gradient), as ``(C, colsum)``; the
+    sums come out of the GEMM epilogue where the library supports it, otherwise from a separate pass over C; either
+    way they are final only after ``colsum_defer.flush()``."""
     _chk(A, "A"); _chk(B, "B", A.dtype)
     out_dtype = out_dtype or A.dtype
     if split_k > 1:
@@ -88,8 +92,19 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     d.tab1 = 0 if tab1 is None else _chk(tab1, "tab1", torch.float32).data_ptr()
     d.tab2 = 0 if tab2 is None else _chk(tab2, "tab2", torch.float32).data_ptr()
     d.tab_L = tab_L
+    if colsum_defer is None:
+        L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
+        return out
+    nrows = L.lib().xp_gemm_colsum_rows(C.byref(d))
+    if nrows == 0:
+        L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
+        return out, colsum_deferred(out, M, N, colsum_defer, ldx=d.ldc)
+    cs = torch.empty(N, dtype=torch.float32, device=A.device)
+    part = colsum_defer.slot(nrows * N * 4)
+    d.colsum_partials = part.data_ptr()
     L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
-    return out
+    colsum_defer.add(part, 0, cs, nrows, N, N)
+    return out, cs
 
 
 def gemm_auto_split(M: int, N: int, K: int, dtype: torch.dtype, *, a_kstrided=True, b_kstrided=True, lda=None,
