@@ -123,10 +123,15 @@ int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, void* workspac
 int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                      float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, void* stream);
 size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
-/* dgamma == dbeta == NULL defers the parameter-gradient reduction: the workspace then holds
- * xp_layernorm_bwd_partial_rows(rows) partial rows of [dgamma(cols) | dbeta(cols)] (pitch 2*cols) for
- * xp_reduce_rows_batch. */
+/* Deferred form: dx is final, the parameter gradients stay as xp_layernorm_bwd_partial_rows(rows) partial rows in
+ * the workspace -- [dgamma(cols) | dbeta(cols)] (pitch 2*cols), or with with_dx_colsum != 0
+ * [dgamma | dbeta | colsum(dx)] (pitch 3*cols; the column sums of the dx just written = the bias gradient of the
+ * Linear in front of this residual add) -- for xp_reduce_rows_batch. */
 int64_t xp_layernorm_bwd_partial_rows(int64_t rows);
+int xp_layernorm_bwd_partials(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                              const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                              void* dx, int64_t lddx, int32_t with_dx_colsum, int64_t rows, int64_t cols,
+                              int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = (dres ? dres : 0) + LN'(dy);  dgamma/dbeta (+)= column sums.  dres may alias dx. */
 int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
                      const float* mean, const float* rstd, const void* dres, int64_t lddres,

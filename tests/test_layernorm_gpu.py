@@ -75,7 +75,11 @@ def test_reduce_rows_batch_and_deferred_producers():
         d = H.DeferredReduce(X.device)
         cs = H.colsum_deferred(X, rows, cols, d)
         dx1, dg1, db1 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, defer=d)
+        dres = torch.randn(rows, cols, device="cuda").to(dtype)
+        dx2, dg2, db2, dxs = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, dres=dres, defer=d, dx_colsum=True)
         d.flush()
+        assert report(f"ln dx colsum {dtype}", dxs, dx2.double().sum(0), 3e-3 if dtype == torch.bfloat16 else 1e-5) <= 3e-3
+        assert report(f"ln dgamma (3-vector partials) {dtype}", dg2, dg1, 2e-6) <= 2e-6
         dx0, dg0, db0 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols)
         assert report(f"colsum deferred {dtype}", cs, H.colsum(X, rows, cols), 2e-6) <= 2e-6
         assert torch.equal(dx0, dx1)

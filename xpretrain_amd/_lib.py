@@ -72,6 +72,7 @@ SIGNATURES = {
     "xp_reduce_rows_batch_workspace_bytes": (sz, [C.POINTER(XpReduceSeg), i32]),
     "xp_reduce_rows_batch": (i32, [C.POINTER(XpReduceSeg), i32, vp, sz, vp]),
     "xp_layernorm_bwd_partial_rows": (i64, [i64]),
+    "xp_layernorm_bwd_partials": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i64, i64, i32, vp, sz, vp]),
     "xp_grad_sqnorm_partials": (i32, [vp, vp, i32, C.POINTER(vp), i32, vp, vp]),
     "xp_adamw_step": (i32, [vp, vp, i32, C.POINTER(vp), C.POINTER(C.c_uint8), i32, C.POINTER(XpAdamGroup), i32, vp, i32, f32,
                             vp, vp]),

@@ -67,16 +67,23 @@ template <> struct Raw4<bf16_t> { typedef bf16x4 type; };
 __device__ __forceinline__ f32x4 cvt4(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 cvt4(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-template <typename T, int NJ>
+// DXS: also accumulate the column sums of the dx this kernel writes (the bias gradient of the Linear whose output feeds
+// the residual stream here); the partial rows are then [dgamma | dbeta | dxsum].
+template <typename T, int NJ, bool DXS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* dres, int64_t lddres,
                                                      T* dx, int64_t lddx, float* __restrict__ part,
                                                      int64_t rows, int cols) {
-  __shared__ float red[WAVES][2][NJ * 256];
+  constexpr int NV = DXS ? 3 : 2;
+  __shared__ float red[WAVES][NV][NJ * 256];
   typedef typename Raw4<T>::type raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 gm[NJ], dg[NJ], db[NJ];
+  f32x4 gm[NJ], dg[NJ], db[NJ], dxs[DXS ? NJ : 1];
+  if constexpr (DXS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dxs[j] = f32x4{0, 0, 0, 0};
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = j * 256 + lane * 4;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs[u] * (gy[j][e] - c1 - xh[j][e] * c2) + rv[e];
           store4(dx + rws[u] * lddx + c, o);
+          if constexpr (DXS) dxs[j] += o;
         }
       }
     }
@@ -141,15 +149,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < cols) { store4(&red[wave][0][c], dg[j]); store4(&red[wave][1][c], db[j]); }
+    if (c < cols) {
+      store4(&red[wave][0][c], dg[j]); store4(&red[wave][1][c], db[j]);
+      if constexpr (DXS) store4(&red[wave][2][c], dxs[j]);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-    float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) { a += red[w][0][c]; b += red[w][1][c]; }
-    part[((int64_t)blockIdx.x * 2 + 0) * cols + c] = a;
-    part[((int64_t)blockIdx.x * 2 + 1) * cols + c] = b;
+    for (int q = 0; q < NV; ++q) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) a += red[w][q][c];
+      part[((int64_t)blockIdx.x * NV + q) * cols + c] = a;
+    }
   }
 }
 
@@ -216,37 +229,50 @@ extern "C" int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
   return XP_OK;
 }
 
-extern "C" int64_t xp_layernorm_bwd_partial_rows(int64_t rows) { return bwd_blocks(rows); }
-
 extern "C" size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
-  return (size_t)(bwd_blocks(rows) + 32) * 2 * cols * sizeof(float);
+  return (size_t)(bwd_blocks(rows) + 32) * 3 * cols * sizeof(float);
 }
+
+namespace {
+int ln_bwd_launch(const char* name, const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
+                  const float* rstd, const void* dres, int64_t lddres, void* dx, int64_t lddx, int64_t rows, int64_t cols,
+                  int32_t dtype, bool dxs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  XP_REQUIRE(dy && x && gamma && mean && rstd && dx, "%s: null pointer", name);
+  XP_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXJ * 256, "%s: cols=%lld unsupported", name, (long long)cols);
+  XP_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "%s: ld must be a multiple of 4", name);
+  XP_REQUIRE(workspace && workspace_bytes >= xp_layernorm_bwd_workspace_bytes(rows, cols), "%s: workspace too small", name);
+  XP_REQUIRE(dtype == XP_BF16 || dtype == XP_F32, "%s: bad dtype %d", name, dtype);
+  const int blocks = bwd_blocks(rows);
+  float* part = (float*)workspace;
+  const int nj = (int)cdiv(cols, 256);
+#define XP_LN_BWD(T, NJ, D)                                                                                           \
+  ln_bwd_kernel<T, NJ, D><<<blocks, 256, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, gamma, mean, rstd, (const T*)dres, \
+                                                  lddres, (T*)dx, lddx, part, rows, (int)cols)
+#define XP_LN_BWD_NJ(T, D)                                                                                            \
+  do { if (nj == 1) XP_LN_BWD(T, 1, D); else if (nj == 2) XP_LN_BWD(T, 2, D); else if (nj == 3) XP_LN_BWD(T, 3, D); else XP_LN_BWD(T, 4, D); } while (0)
+  if (dtype == XP_BF16) { if (dxs) XP_LN_BWD_NJ(bf16_t, true); else XP_LN_BWD_NJ(bf16_t, false); }
+  else                  { if (dxs) XP_LN_BWD_NJ(float, true);  else XP_LN_BWD_NJ(float, false); }
+#undef XP_LN_BWD_NJ
+#undef XP_LN_BWD
+  XP_CHECK_LAUNCH(name);
+  return XP_OK;
+}
+}  // namespace
 
 extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
                                 const float* mean, const float* rstd, const void* dres, int64_t lddres,
                                 void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                                 int64_t rows, int64_t cols, int32_t dtype,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-  XP_REQUIRE(dy && x && gamma && mean && rstd && dx, "xp_layernorm_bwd: null pointer");
-  XP_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), "xp_layernorm_bwd: dgamma and dbeta must both be given or both be NULL");
-  XP_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXJ * 256, "xp_layernorm_bwd: cols=%lld unsupported", (long long)cols);
-  XP_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "xp_layernorm_bwd: ld must be a multiple of 4");
-  XP_REQUIRE(workspace && workspace_bytes >= xp_layernorm_bwd_workspace_bytes(rows, cols), "xp_layernorm_bwd: workspace too small");
-  const int blocks = bwd_blocks(rows);
+  XP_REQUIRE(dgamma && dbeta, "xp_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)workspace;
-  XP_REQUIRE(dtype == XP_BF16 || dtype == XP_F32, "xp_layernorm_bwd: bad dtype %d", dtype);
-  const int nj = (int)cdiv(cols, 256);
-#define XP_LN_BWD(T, NJ)                                                                                             \
-  ln_bwd_kernel<T, NJ><<<blocks, 256, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, gamma, mean, rstd, (const T*)dres, \
-                                               lddres, (T*)dx, lddx, part, rows, (int)cols)
-  if (dtype == XP_BF16) { if (nj == 1) XP_LN_BWD(bf16_t, 1); else if (nj == 2) XP_LN_BWD(bf16_t, 2); else if (nj == 3) XP_LN_BWD(bf16_t, 3); else XP_LN_BWD(bf16_t, 4); }
-  else                  { if (nj == 1) XP_LN_BWD(float, 1);  else if (nj == 2) XP_LN_BWD(float, 2);  else if (nj == 3) XP_LN_BWD(float, 3);  else XP_LN_BWD(float, 4); }
-#undef XP_LN_BWD
-  XP_CHECK_LAUNCH("xp_layernorm_bwd");
-  if (!dgamma) return XP_OK;       // deferred: the caller reduces the partial rows (xp_reduce_rows_batch)
+  int rc = ln_bwd_launch("xp_layernorm_bwd", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype, false,
+                         workspace, workspace_bytes, st);
+  if (rc) return rc;
   // two-level deterministic reduce of the per-block partial rows: blocks -> <=32 -> 1; dgamma/dbeta may be two
   // separate buffers, so the last level runs once per output
+  const int blocks = bwd_blocks(rows);
+  float* part = (float*)workspace;
   const int width = 2 * (int)cols, lvl = (int)cdiv(blocks, 32);
   float* part2 = part + (int64_t)blocks * width;
   ln_param_reduce_kernel<<<dim3((unsigned)cdiv(width, 64), (unsigned)cdiv(blocks, lvl)), 256, 0, st>>>(part, part2, blocks, lvl, width, 0);
@@ -256,4 +282,14 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
   ln_param_reduce2_kernel<<<(unsigned)cdiv(width, 64), 256, 0, st>>>(part2, dgamma, dbeta, n2, (int)cols, accumulate);
   XP_CHECK_LAUNCH("xp_layernorm_bwd(reduce2)");
   return XP_OK;
+}
+
+extern "C" int64_t xp_layernorm_bwd_partial_rows(int64_t rows) { return bwd_blocks(rows); }
+
+extern "C" int xp_layernorm_bwd_partials(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                                         const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                                         void* dx, int64_t lddx, int32_t with_dx_colsum, int64_t rows, int64_t cols,
+                                         int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  return ln_bwd_launch("xp_layernorm_bwd_partials", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype,
+                       with_dx_colsum != 0, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -209,11 +209,12 @@ class EncoderLayerFn(torch.autograd.Function):
         db2 = H.colsum_deferred(dx3, rows, D, defer)
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
         dw1 = _wgrad(dpre, h2, rows, Dff, D)
-        dx2, dln2_w, dln2_b = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer)
+        # out_proj's bias gradient = column sums of dx2: accumulated by the LayerNorm backward that writes dx2
+        dx2, dln2_w, dln2_b, dbo = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
+                                                   dx_colsum=True)
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
         dwo = _wgrad(dx2, attn_o, rows, D, D)
-        dbo = H.colsum_deferred(dx2, rows, D, defer)
         dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
         dh1 = H.gemm(dqkv, Wqkv, rows, D, 3 * D, b_kstrided=True)
         dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)

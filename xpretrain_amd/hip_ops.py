@@ -201,7 +201,8 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, dres=None, dx=None, lddx=None,
-                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None):
+                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None, dx_colsum=False):
+    """Returns (dx, dgamma, dbeta) -- plus colsum(dx) when ``dx_colsum`` (deferred mode only)."""
     _chk(dy, "dy"); _chk(x, "x", dy.dtype)
     dx = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device) if dx is None else dx
     dgamma = torch.empty(cols, dtype=torch.float32, device=dy.device) if dgamma is None else dgamma
@@ -209,13 +210,20 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, 
     nb = L.lib().xp_layernorm_bwd_workspace_bytes(rows, cols)
     if defer is not None:     # parameter-gradient partial rows stay in their own slot until defer.flush()
         ws = defer.slot(nb)
-        L.check(L.lib().xp_layernorm_bwd(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
-                                         _p(dres), cols, _p(dx), lddx or cols, None, None, 0,
-                                         rows, cols, _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd")
+        L.check(L.lib().xp_layernorm_bwd_partials(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
+                                                  _p(dres), cols, _p(dx), lddx or cols, int(dx_colsum), rows, cols,
+                                                  _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd_partials")
         nrows = L.lib().xp_layernorm_bwd_partial_rows(rows)
-        defer.add(ws, 0, dgamma, nrows, cols, 2 * cols, accumulate)
-        defer.add(ws, cols, dbeta, nrows, cols, 2 * cols, accumulate)
+        pitch = (3 if dx_colsum else 2) * cols
+        defer.add(ws, 0, dgamma, nrows, cols, pitch, accumulate)
+        defer.add(ws, cols, dbeta, nrows, cols, pitch, accumulate)
+        if dx_colsum:
+            dxs = torch.empty(cols, dtype=torch.float32, device=dy.device)
+            defer.add(ws, 2 * cols, dxs, nrows, cols, pitch)
+            return dx, dgamma, dbeta, dxs
         return dx, dgamma, dbeta
+    if dx_colsum:
+        raise ValueError("layernorm_bwd: dx_colsum needs a DeferredReduce")
     ws = workspace(nb, dy.device, "ln")
     L.check(L.lib().xp_layernorm_bwd(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
                                      _p(dres), cols, _p(dx), lddx or cols, _p(dgamma), _p(dbeta), int(accumulate),
