@@ -158,14 +158,11 @@ int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* s
                 int64_t M, int64_t N, int64_t L, int32_t dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
 /* dqkv[B,S,3,H,64] (same layout as qkv; dq already multiplied by q_scale so it is the gradient of the
- * un-scaled projection output).  colsum_partials (nullable): xp_attn_bwd_colsum_rows() partial rows of
- * 3*H*64 floats whose column sums are sum_tokens dqkv -- the fused q/k/v bias gradient (autograd: grad.sum(0) of
- * q_proj/k_proj/v_proj, CLIP_ViP.py:341-343) without re-reading dqkv; finish with xp_reduce_rows_batch. */
-int64_t xp_attn_bwd_colsum_rows(int32_t mode, int64_t B, int64_t S, int64_t M, int64_t N, int64_t L);
+ * un-scaled projection output). */
 int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
                 const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
                 int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
-                float* colsum_partials, void* workspace, size_t workspace_bytes, void* stream);
+                void* workspace, size_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------------------------- Embeddings / glue
  * CLIPVisionViPEmbeddings.forward (modeling/CLIP_ViP.py:168-197).

@@ -84,8 +84,7 @@ SIGNATURES = {
     "xp_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i64, i64, i32, vp, sz, vp]),
     "xp_attn_workspace_bytes": (sz, [i32, i64, i64, i64, i64, i64]),
     "xp_attn_fwd": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
-    "xp_attn_bwd_colsum_rows": (i64, [i32, i64, i64, i64, i64, i64]),
-    "xp_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp, sz, vp]),
+    "xp_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
     "xp_im2col": (i32, [vp, vp, i64, i64, i64, i64, i32, vp]),
     "xp_im2col_u8": (i32, [vp, C.POINTER(f32), C.POINTER(f32), vp, i64, i64, i64, i64, i32, vp]),
     "xp_vip_proxy_rows": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]),

@@ -44,7 +44,6 @@ struct AP {
   int nq, nprob;                        // forward: query blocks per problem, problems
   float q_scale;
   float* ws0; float* ws1; float* ws2;   // fwd: partials | bwd: delta, dq partials, dkv partials
-  float* cs; int cs_ld;                 // bwd, optional: column-sum partial rows of dqkv (bias gradient), pitch 3*H*64
 };
 
 struct Prob {
@@ -424,34 +423,6 @@ __device__ __forceinline__ bool wg_problem(const AP& p, int& prob, int& blk) {
   return prob < p.nprob;
 }
 
-// Column sums of a workgroup's own-row gradients (NV sets of 64 d-values per row): 16-row reduction inside each wave by
-// lane butterflies, then across the 7 waves through LDS (the staging area is idle by now); thread t < NV*64 writes
-// dst[t / 64 * part_stride + t % 64].  Every wave of the workgroup must call this.
-template <int NV>
-__device__ __forceinline__ void wg_colsum(const f32x4 (&v)[NV][4], char* smem, float* dst, int64_t part_stride, int tid) {
-  const int lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-  float* red = reinterpret_cast<float*>(smem);
-  __syncthreads();                                    // all waves are done reading the staged tiles
-#pragma unroll
-  for (int q = 0; q < NV; ++q)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 x = v[q][dt];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] += __shfl_xor(x[e], o, 64);
-      if (i16 == 0) store4(red + (wave * NV + q) * 64 + dt * 16 + 4 * g, x);
-    }
-  __syncthreads();
-  if (tid < NV * 64) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < FW; ++w) s += red[w * NV * 64 + tid];
-    dst[(tid >> 6) * part_stride + (tid & 63)] = s;
-  }
-}
-
 // ---- dK, dV: the workgroup owns 112 key rows; loops over the problem's query rows (Q, dO, m, log l, delta staged) ----
 struct DkvState { f32x4 dk[4], dv[4]; };
 
@@ -591,17 +562,6 @@ __global__ __launch_bounds__(FTHR, 4) void attn_bwd_dkv_kernel(AP p) {
       else              dkv_step<2>(st, p, pr, gQ, gDO, gM, gLg, gDl, kf, vf, t0, qb, rk, kvalid, kpad, wkey0, lane);
     }
   }
-  if (p.cs) {       // bias-gradient partials: sums of this workgroup's dK / dV rows (proxy rows are added by the proxy reduce)
-    const bool own = kvalid && !(p.mode == XP_ATTN_PROXY && rk < p.M);
-    f32x4 v[2][4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      v[0][dt] = own ? st.dk[dt] : f32x4{0, 0, 0, 0};
-      v[1][dt] = own ? st.dv[dt] : f32x4{0, 0, 0, 0};
-    }
-    const int64_t row = ((int64_t)pr.b * p.N + pr.n) * p.nq + blk;
-    wg_colsum<2>(v, smem, p.cs + row * p.cs_ld + (int64_t)p.H * DH + pr.h * DH, (int64_t)p.H * DH, tid);
-  }
   if (!kvalid) return;
   if (p.mode == XP_ATTN_PROXY && rk < p.M) {
     float* part = p.ws2 + ((int64_t)prob * p.M + rk) * (2 * DH);
@@ -721,14 +681,6 @@ __global__ __launch_bounds__(FTHR, 4) void attn_bwd_dq_kernel(AP p) {
       else         dq_step<4>(dq, p, pr, gK, gV, gPad, qf, dof, mq, lgq, dlq, t0, kb, rq, qvalid, wrow0, lane);
     }
   }
-  if (p.cs) {
-    const bool own = qvalid && !(p.mode == XP_ATTN_PROXY && rq < p.M);
-    f32x4 v[1][4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) v[0][dt] = own ? dq[dt] * p.q_scale : f32x4{0, 0, 0, 0};
-    const int64_t row = ((int64_t)pr.b * p.N + pr.n) * p.nq + blk;
-    wg_colsum<1>(v, smem, p.cs + row * p.cs_ld + pr.h * DH, 0, tid);
-  }
   if (!qvalid) return;
   if (p.mode == XP_ATTN_PROXY && rq < p.M) {
     float* part = p.ws1 + ((int64_t)prob * p.M + rq) * DH;
@@ -756,10 +708,6 @@ __global__ void attn_bwd_proxy_reduce_kernel(AP p) {
   base[0] = (bf16_t)(q * p.q_scale);
   base[(int64_t)p.H * DH] = (bf16_t)k;
   base[(int64_t)2 * p.H * DH] = (bf16_t)v;
-  if (p.cs) {       // the proxy rows' own partial rows, after the per-workgroup ones
-    float* c = p.cs + ((int64_t)(p.nprob / p.H) * p.nq + (int64_t)b * p.M + mrow) * p.cs_ld + h * DH + d;
-    c[0] = q * p.q_scale; c[(int64_t)p.H * DH] = k; c[(int64_t)2 * p.H * DH] = v;
-  }
 }
 
 int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L,
@@ -816,15 +764,10 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   return XP_OK;
 }
 
-extern "C" int64_t xp_attn_bwd_colsum_rows(int32_t mode, int64_t B, int64_t S, int64_t M, int64_t N, int64_t L) {
-  if (mode == XP_ATTN_CAUSAL) return B * cdiv(S, FQ);
-  return B * N * cdiv(M + L, FQ) + B * M;
-}
-
 extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
                            const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
                            int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
-                           float* colsum_partials, void* workspace, size_t workspace_bytes, void* stream) {
+                           void* workspace, size_t workspace_bytes, void* stream) {
   XP_REQUIRE(qkv && out && dout && stats && dqkv, "xp_attn_bwd: null pointer");
   if (mode == XP_ATTN_CAUSAL) { M = 0; N = 1; L = S; }
   int rc = check_common("xp_attn_bwd", mode, B, H, S, M, N, L, ldqkv, ldo, dtype);
@@ -837,7 +780,6 @@ extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, cons
   p.R = mode == XP_ATTN_PROXY ? (int)(M + L) : (int)S;
   const int64_t P = B * H * N;
   p.ws0 = (float*)workspace; p.ws1 = p.ws0 + B * H * S; p.ws2 = p.ws1 + P * M * DH;
-  p.cs = colsum_partials; p.cs_ld = (int)(3 * H * DH);
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)P;
   const unsigned grid = (unsigned)(cdiv(p.nprob, 8) * 8 * p.nq);

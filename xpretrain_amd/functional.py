@@ -215,11 +215,10 @@ class EncoderLayerFn(torch.autograd.Function):
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
         dwo = _wgrad(dx2, attn_o, rows, D, D)
-        # the fused q/k/v bias gradient = column sums of dqkv: summed per workgroup inside the attention backward
-        dqkv, dbqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale,
-                                 colsum_defer=defer)
+        dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
         dh1 = H.gemm(dqkv, Wqkv, rows, D, 3 * D, b_kstrided=True)
         dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)
+        dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer)
         dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer)
         defer.flush()
         dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]

@@ -421,21 +421,12 @@ def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, *, size=None, pad_mask=N
     return out, stats
 
 
-def attn_bwd(qkv, out, dout, stats, B, S, H, *, size=None, pad_mask=None, q_scale=1.0, colsum_defer=None):
-    """dqkv -- or (dqkv, column sums of dqkv = the fused q/k/v bias gradient, final after ``colsum_defer.flush()``)."""
+def attn_bwd(qkv, out, dout, stats, B, S, H, *, size=None, pad_mask=None, q_scale=1.0):
     mode = L.ATTN_PROXY if size is not None else L.ATTN_CAUSAL
     M, N, Lp = size if size is not None else (0, 1, S)
     dqkv = torch.empty_like(qkv)
     ws = _attn_ws(mode, B, H, M, N, Lp, qkv.device)
-    part = None
-    if colsum_defer is not None:
-        nrows = L.lib().xp_attn_bwd_colsum_rows(mode, B, S, M, N, Lp)
-        part = colsum_defer.slot(nrows * 3 * H * 64 * 4)
     L.check(L.lib().xp_attn_bwd(_p(qkv), 3 * H * 64, _p(out), _p(dout), H * 64, _p(stats), _p(pad_mask), _p(dqkv),
-                                float(q_scale), mode, B, H, S, M, N, Lp, _dt(qkv), _p(part), _p(ws), ws.numel(),
-                                _stream()), "xp_attn_bwd")
-    if colsum_defer is None:
-        return dqkv
-    cs = torch.empty(3 * H * 64, dtype=torch.float32, device=qkv.device)
-    colsum_defer.add(part, 0, cs, nrows, 3 * H * 64, 3 * H * 64)
-    return dqkv, cs
+                                float(q_scale), mode, B, H, S, M, N, Lp, _dt(qkv), _p(ws), ws.numel(), _stream()),
+            "xp_attn_bwd")
+    return dqkv
