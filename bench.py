@@ -105,6 +105,18 @@ def cpu_baseline(args):
                       f"T={args.frames}/{args.res}^2/Lt={args.txt_len} ViT-B/{args.patch} config, {dt:.1f} s"}
 
 
+def workload_tag(a, W):
+    """which BASELINE.json config the shape corresponds to"""
+    shape = (a.patch, a.frames, a.res, a.txt_len)
+    if shape == (16, 12, 224, 32):
+        return "BASELINE configs[1]" if W == 1 else "BASELINE configs[2] (configs[1] per GPU)"
+    if shape == (16, 8, 448, 32):
+        return "BASELINE configs[3] shape"
+    if shape == (16, 32, 224, 32):
+        return "BASELINE configs[4] shape"
+    return "custom shape"
+
+
 def main():
     a = parse()
     from xpretrain_amd import distributed as D
@@ -225,7 +237,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"CLIP-ViP ViT-B/{a.patch} video-text contrastive train step (fwd+loss+bwd+grad-sync+"
                                    f"clip+AdamW), {a.frames} frames {a.res}^2, {a.txt_len} text tokens, "
-                                   f"local batch {a.batch}, BASELINE configs[1]" + ("" if W == 1 else "/[2]"),
+                                   f"local batch {a.batch}, " + workload_tag(a, W),
                        "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4),
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager"},
             "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
