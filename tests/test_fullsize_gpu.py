@@ -1,0 +1,66 @@
+"""GPU: BASELINE config #2 at FULL size (ViT-B/16, 12 frames 224^2, 32 text tokens, batch 8) -- the oracle takes minutes
+there, so the step is checked through size-independent properties:
+
+* run-to-run determinism: features, loss and EVERY parameter gradient are bit-identical (all reductions are fixed-order);
+* batch-permutation equivariance, bit-exact: every kernel treats samples independently and a row's accumulation order
+  does not depend on where its tile sits;
+* unit-norm features; the fused loss kernel equals the oracle's loss formula evaluated on the same (GPU) features;
+* optimizer round trip: after clip + AdamW the bf16 weight shadows equal the cast of the updated fp32 masters.
+"""
+import pytest
+import torch
+
+from oracle import clipvip_oracle as O
+from tests.test_model_gpu import _Args
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, loss_fn, video, ids, mask):
+    for p in model.parameters():
+        p.grad = None
+    out = model(video, ids, mask)
+    loss = loss_fn(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    return out["vis_features"].detach().clone(), out["text_features"].detach().clone(), loss.detach().clone(), grads
+
+
+def test_cfg2_full_size_properties():
+    from xpretrain_amd.functional import WEIGHTS
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import AdamW, NCELearnableTempLoss
+    torch.manual_seed(1234)
+    model = VidCLIP(_Args(O.vit_b_config(16, 224), 12)).cuda().train()
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.02)
+    video, ids, mask = O.synthetic_inputs(8, 12, 224, 32)
+    video, ids, mask = video.cuda(), ids.cuda(), mask.cuda()
+    loss_fn = NCELearnableTempLoss()
+
+    v1, t1, l1, g1 = _run(model, loss_fn, video, ids, mask)
+    v2, t2, l2, g2 = _run(model, loss_fn, video, ids, mask)
+    assert torch.equal(v1, v2) and torch.equal(t1, t2) and torch.equal(l1, l2), "forward is not deterministic"
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), f"gradient of {n} is not deterministic"
+
+    perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4], device="cuda")
+    with torch.no_grad():
+        o = model(video[perm], ids[perm], mask[perm])
+    assert torch.equal(o["vis_features"], v1[perm]) and torch.equal(o["text_features"], t1[perm]), "not batch-equivariant"
+
+    assert (v1.norm(dim=-1) - 1).abs().max().item() < 1e-5 and (t1.norm(dim=-1) - 1).abs().max().item() < 1e-5
+    ref = O.nce_learnable_temp_loss(v1.cpu().double(), t1.cpu().double(), model.clipmodel.logit_scale.detach().cpu().double())
+    assert abs(l1.item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item()))
+    assert all(torch.isfinite(g).all() for g in g1.values())
+
+    opt = AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+    norm = opt.clip_and_step(5.0)
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in g1.values()))
+    assert abs(norm.item() - total.item()) <= 1e-4 * total.item()
+    layer = model.clipmodel.vision_model.encoder.layers[5]
+    bf = torch.bfloat16
+    a = layer.self_attn
+    assert torch.equal(WEIGHTS.fused((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), bf),
+                       torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight]).detach().to(bf))
+    assert torch.equal(WEIGHTS.get(layer.mlp.fc1.weight, bf), layer.mlp.fc1.weight.detach().to(bf))
