@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Post-compile lint of the inline-asm LDS transpose reads (csrc/common.h::lds_read_tr16_async).
+
+The asm `ds_read_b64_tr_b16` is invisible to hipcc's waitcnt bookkeeping, so the source places an explicit
+`s_waitcnt lgkmcnt(0)` before the first use of its result.  This script checks the GENERATED code: between every
+`ds_read_b64_tr_b16 v[a:b], ...` that came from inline asm (marked by the `;;#ASMSTART` / `;;#ASMEND` pair hipcc emits) and
+the next `s_waitcnt` that waits lgkmcnt(0), no instruction may mention v[a..b] as an operand.  Usage:
+    check_isa.py file.s [file2.s ...]      exit status 1 on a violation
+"""
+import re
+import sys
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check(path):
+    bad = 0
+    pending = {}          # register -> line number of the asm read that wrote it
+    in_asm = False
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.split(";")[0].strip() if not raw.lstrip().startswith(";;#") else raw.strip()
+        if raw.lstrip().startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if raw.lstrip().startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not line or line.endswith(":") or line.startswith("."):
+            continue          # labels: the scan is linear in layout order (the kernels read and wait in one block or fall through)
+        if in_asm and line.startswith("ds_read_b64_tr_b16"):
+            dst = line.split(",")[0]
+            for r in regs_of(dst):
+                pending[r] = ln
+            continue
+        if line.startswith("s_waitcnt") and "lgkmcnt(0)" in line:
+            pending.clear()
+            continue
+        if line.startswith("s_endpgm"):
+            pending.clear()
+            continue
+        if pending:
+            used = regs_of(line) & set(pending)
+            if used:
+                print(f"{path}:{ln}: `{line}` touches v{sorted(used)} written by the asm transpose read at line "
+                      f"{pending[min(used)]} before s_waitcnt lgkmcnt(0)")
+                bad += 1
+    return bad
+
+
+if __name__ == "__main__":
+    total = sum(check(p) for p in sys.argv[1:])
+    print(f"check_isa: {len(sys.argv) - 1} file(s), {total} violation(s)")
+    sys.exit(1 if total else 0)

@@ -126,3 +126,16 @@ __device__ __forceinline__ i16x4 lds_read_tr16(const void* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) i16x4*)(lds_ptr));
 }
+// The same read as inline asm, for loops that keep `buffer_load ... lds` DMA in flight: hipcc's waitcnt pass puts
+// `s_waitcnt vmcnt(0)` in front of every ds_read_tr builtin while an LDS-DMA is outstanding (plain ds_read_b128 is not
+// affected), which drains the whole prefetch pipeline once per phase.  The asm form is invisible to that pass -- and to
+// its lgkmcnt bookkeeping: the CALLER must execute `s_waitcnt lgkmcnt(0)` before the first use of the result, and
+// tools/check_isa.py (run by the build) verifies in the generated code that nothing touches the destination registers
+// before that wait.  OFF = immediate byte offset (< 65536).
+template <int OFF>
+__device__ __forceinline__ i16x4 lds_read_tr16_async(const void* lds_ptr) {
+  const unsigned addr = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(lds_ptr));
+  i16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}

@@ -105,8 +105,9 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int ot, int ks, int lan
     const int f = (i >> 2) | ((g & 1) << 2);
     const int kr = ks * 32 + g * 8 + (i >> 2);
     const char* p = tile + kr * RB + ((ot ^ f) << 5) + ((i & 3) << 3);
-    i16x4 lo = lds_read_tr16(p);
-    i16x4 hi = lds_read_tr16(p + 4 * RB);
+    // asm reads (no compiler-inserted vmcnt(0) beside the DMA ring); consumed after XP_PHASE_MMA's s_waitcnt lgkmcnt(0)
+    i16x4 lo = lds_read_tr16_async<0>(p);
+    i16x4 hi = lds_read_tr16_async<4 * RB>(p);
     typedef __attribute__((ext_vector_type(8))) short i16x8;
     i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
