@@ -97,3 +97,47 @@ def test_adamw_rewrites_weight_shadows_and_skips_casts():
         assert torch.equal(WEIGHTS.get(other, bf), other.detach().to(bf))     # re-cast after the foreign step
         assert torch.equal(WEIGHTS.get(frozen, bf), frozen.detach().to(bf))
     assert "exp_avg" not in opt.state[frozen]
+
+
+def test_adamw_state_dict_round_trip():
+    """E2E_TrainingRestorer-style resume (utils/load_save.py:306-314): optimizer.state_dict() -> a NEW optimizer ->
+    load_state_dict -> the next steps equal the uninterrupted run (the step plan must follow the replaced state tensors)."""
+    from xpretrain_amd.optimization import AdamW
+    torch.manual_seed(2)
+    shapes = [(33, 17), (17,), (), (300, 70)]
+    init = [torch.randn(s) * 0.1 for s in shapes]
+    grads = [[torch.randn(s) * 0.1 for s in shapes] for _ in range(4)]
+
+    def make():
+        ps = [torch.nn.Parameter(p.clone().cuda()) for p in init]
+        return ps, AdamW([dict(params=ps[:2], weight_decay=0.1), dict(params=ps[2:], weight_decay=0.0)], lr=1e-2)
+
+    def run(ps, opt, gs):
+        for g in gs:
+            for p, x in zip(ps, g):
+                p.grad = x.clone().cuda()
+            opt.clip_and_step(1.0)
+
+    pa, oa = make()
+    run(pa, oa, grads)                                   # uninterrupted
+    pb, ob = make()
+    run(pb, ob, grads[:2])
+    sd = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in ob.state_dict().items()}     # as torch.save / load would
+    sd["state"] = {i: {k: (v.cpu().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in ob.state_dict()["state"].items()}
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    oc = AdamW([dict(params=pc[:2], weight_decay=0.1), dict(params=pc[2:], weight_decay=0.0)], lr=1e-2)
+    oc.load_state_dict(sd)
+    run(pc, oc, grads[2:])
+    for a, c in zip(pa, pc):
+        assert torch.equal(a.detach(), c.detach())
+    assert all(oc.state[p]["step"] == 4 for p in pc)
+    run(pb, ob, grads[2:])                               # and load_state_dict into a LIVE optimizer that already has a plan
+    import copy
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))   # deep copy: load_state_dict keeps same-device tensors by reference
+    for p, x in zip(pb, grads[0]):
+        p.grad = x.clone().cuda()
+    for p, x in zip(pa, grads[0]):
+        p.grad = x.clone().cuda()
+    ob.clip_and_step(1.0); oa.clip_and_step(1.0)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.detach(), b.detach())

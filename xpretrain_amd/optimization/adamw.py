@@ -58,10 +58,8 @@ class AdamW(Optimizer):
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
                 raise TypeError("xpretrain_amd AdamW: parameters must be contiguous fp32 tensors on one device")
             st = self.state[p]
-            if len(st) == 0:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p.data)
-                st["exp_avg_sq"] = torch.zeros_like(p.data)
+            if st["exp_avg"].dtype != torch.float32 or not st["exp_avg"].is_contiguous() or st["exp_avg"].device != dev:
+                raise TypeError("xpretrain_amd AdamW: optimizer state must be contiguous fp32 tensors on the parameter's device")
             tensors.append((gi, p, st))
         n_total_chunks = 0
         for i0 in range(0, len(tensors), L.XP_OPT_MAX_TENSORS):
@@ -87,7 +85,11 @@ class AdamW(Optimizer):
                     norm=torch.zeros((), dtype=torch.float32, device=dev))
 
     def _plan_key(self, act, cache):
-        return (tuple((gi, id(p), p.data_ptr()) for gi, p in act), cache.structure_version)
+        # parameter storage, moment storage (load_state_dict replaces the state tensors) and the weight cache's buffers
+        def moments(p):
+            st = self.state.get(p)
+            return (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) if st and "exp_avg" in st else (0, 0)
+        return (tuple((gi, id(p), p.data_ptr()) + moments(p) for gi, p in act), cache.structure_version)
 
     # ------------------------------------------------------------------------------------------ step
     @torch.no_grad()
@@ -100,6 +102,12 @@ class AdamW(Optimizer):
         if not act:
             return loss
         from ..functional import WEIGHTS
+        for _, p in act:                     # state initialisation (adamw.py:62-68) before the plan key looks at it
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p.data)
+                st["exp_avg_sq"] = torch.zeros_like(p.data)
         if self._plan is None or self._plan["key"] != self._plan_key(act, WEIGHTS):
             self._plan = self._build_plan(act, WEIGHTS)
         plan = self._plan
