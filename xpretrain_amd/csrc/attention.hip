@@ -12,26 +12,21 @@
 // Data layout: qkv[B,S,3,H,64] exactly as the fused QKV GEMM writes it (128 contiguous bytes per
 // (token, head)); out/dout [B,S,H*64]; stats[B,H,S,2] = (row max, log row sum).
 //
-// Kernel structure (flash style, no S x S matrix in memory):
-//   fwd : workgroup = 64 query rows (4 waves x 16), loop over 64-key tiles staged in LDS (XOR-swizzled
-//         128-byte rows).  Scores are computed TRANSPOSED (S^T = K Q^T) so that each lane owns one query
+// Kernel structure (flash style, no S x S matrix in memory): every kernel owns 7 waves x 16 OWN rows of one problem
+// and walks the OTHER dimension, staged in LDS (XOR-swizzled 128-byte rows) in groups of up to 208 rows.
+//   fwd : own = queries.  Scores are computed TRANSPOSED (S^T = K Q^T) so that each lane owns one query
 //         column: the online-softmax statistics are per-lane scalars and the bf16 P values are already the
 //         B-operand fragment of the P.V MFMA -- no cross-lane shuffles or LDS round trip for P.  V^T
 //         fragments come straight out of the row-major V tile through ds_read_b64_tr_b16.
-//   bwd : two passes, no atomics (deterministic).  dKV: workgroup = 64 keys, loops over query tiles
-//         (S = Q K^T orientation so P/dS are again B-operand fragments).  dQ: workgroup = 64 queries,
-//         loops over key tiles (transposed orientation).  Proxy-token partials are reduced over frames by
-//         a small kernel.
+//   bwd : two passes, no atomics (deterministic).  dQ: own = queries (transposed orientation; also computes
+//         delta = rowsum(dO * O)), then dK/dV: own = keys (S = Q K^T orientation so P/dS are again B-operand
+//         fragments).  Proxy-token partials are reduced over frames by a small kernel.
 #include "common.h"
 #include <math.h>
 
 namespace {
 
 constexpr int DH = 64;
-constexpr int TQ = 256;           // own-dimension rows per workgroup: 16 waves x 16 rows
-constexpr int NTHR = 1024;
-constexpr int GR = 256;           // other-dimension rows staged in LDS per load phase (4 tiles of 64)
-constexpr int TILE = 64 * 128;    // bytes of one [64][64] bf16 tile
 constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(float32).min, _expand_mask (:50-61)
 
 struct AP {
@@ -63,76 +58,6 @@ __device__ __forceinline__ bool allowed(const AP& p, int n, int rq, int rk) {
   return rk <= rq;
 }
 
-// ---- cooperative tile load: 64 problem rows x 64 bf16 (q, k or v slice `which`, or out/dout) -> LDS ---------
-__device__ __forceinline__ void load_tile_qkv(char* tile, const AP& p, const Prob& pr, int which, int row0, int tid) {
-  const int c = tid & 7, rr = tid >> 3;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = rr + 32 * j, r = row0 + row;
-    u32x4 v = {0, 0, 0, 0};
-    if (r < p.R) {
-      const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
-      v = *reinterpret_cast<const u32x4*>(p.qkv + t * p.ldqkv + (int64_t)which * p.H * DH + pr.h * DH + c * 8);
-    }
-    *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = v;
-  }
-}
-__device__ __forceinline__ void load_tile_o(char* tile, const bf16_t* src, const AP& p, const Prob& pr, int row0, int tid) {
-  const int c = tid & 7, rr = tid >> 3;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = rr + 32 * j, r = row0 + row;
-    u32x4 v = {0, 0, 0, 0};
-    if (r < p.R) {
-      const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
-      v = *reinterpret_cast<const u32x4*>(src + t * p.ldo + pr.h * DH + c * 8);
-    }
-    *reinterpret_cast<u32x4*>(tile + tile128_off(row, c)) = v;
-  }
-}
-// ---- cooperative GROUP load: up to GR = 256 problem rows x 64 bf16 -> LDS as 4 swizzled [64][128 B] tiles.  A whole
-// ViT-B/16 frame problem (R = 200 rows) is fetched in ONE latency-bound phase by the 1024 threads (2 x 16 B each per
-// operand) and shared by all 16 waves: no per-tile global round trips, no per-tile barriers.  Rows >= R are zero-filled;
-// only the `ntiles` tiles that will be read are touched.
-__device__ __forceinline__ void load_group(char* base, const bf16_t* src, int64_t ld, int64_t col0, const AP& p,
-                                           const Prob& pr, int row0, int ntiles, int tid) {
-  const int c = tid & 7, rr = tid >> 3;
-  const int nrows = ntiles * 64;
-#pragma unroll
-  for (int j = 0; j < GR / 128; ++j) {
-    const int row = rr + 128 * j, r = row0 + row;
-    if (row < nrows) {
-      u32x4 v = {0, 0, 0, 0};
-      if (r < p.R) {
-        const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
-        v = *reinterpret_cast<const u32x4*>(src + t * ld + col0 + c * 8);
-      }
-      *reinterpret_cast<u32x4*>(base + (row >> 6) * TILE + tile128_off(row & 63, c)) = v;
-    }
-  }
-}
-
-// ---- split tile load (software pipelining): global -> registers is issued one tile AHEAD, under the MFMA work of the
-// current tile; registers -> LDS happens after the barrier that frees the tile.  One exposed global round trip per
-// workgroup instead of one per 64-row tile.
-__device__ __forceinline__ void gload_tile(u32x4 (&v)[2], const bf16_t* src, int64_t ld, int64_t col0, const AP& p,
-                                           const Prob& pr, int row0, int tid) {
-  const int c = tid & 7, rr = tid >> 3;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = row0 + rr + 32 * j;
-    v[j] = u32x4{0, 0, 0, 0};
-    if (r < p.R) {
-      const int64_t t = (int64_t)pr.b * p.S + tok_of(p, pr.n, r);
-      v[j] = *reinterpret_cast<const u32x4*>(src + t * ld + col0 + c * 8);
-    }
-  }
-}
-__device__ __forceinline__ void lstore_tile(char* tile, const u32x4 (&v)[2], int tid) {
-  const int c = tid & 7, rr = tid >> 3;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(tile + tile128_off(rr + 32 * j, c)) = v[j];
-}
 // per-lane register fragment of one row (as MFMA B operand: lane (j = row, g) holds d = 32kk + 8g .. +8)
 __device__ __forceinline__ void load_row_frag(bf16x8 (&f)[2], const bf16_t* rowptr, bool valid, int g) {
 #pragma unroll
