@@ -1,0 +1,74 @@
+"""CPU: the host-side planning entry points of the C ABI (no kernel is launched, no GPU needed): split-K planning,
+fused-column-sum availability, partial-row counts and workspace sizes."""
+import ctypes as C
+
+import pytest
+
+from xpretrain_amd import _lib as L
+
+
+def _desc(M, N, K, *, a_ks=True, b_ks=True, dtype=L.XP_BF16, out=L.XP_F32, epi=L.EPI_NONE, split=1):
+    d = L.XpGemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.lda = M if a_ks else K
+    d.ldb = N if b_ks else K
+    d.ldc = N
+    d.a_kstrided, d.b_kstrided = int(a_ks), int(b_ks)
+    d.in_dtype, d.out_dtype, d.epilogue, d.split_k = dtype, out, epi, split
+    return d
+
+
+def _valid_split(K, s, ke=64):
+    kps = -(-(-(-K // s)) // ke) * ke
+    return -(-K // kps) == s
+
+
+@pytest.mark.parametrize("M,N,K,expect", [(2304, 768, 18848, 9), (768, 768, 18848, 27), (3072, 768, 18848, 7),
+                                          (768, 3072, 18848, 7)])
+def test_auto_split_cfg2_weight_gradients(M, N, K, expect):
+    s = L.lib().xp_gemm_auto_split(C.byref(_desc(M, N, K)))
+    assert s == expect and _valid_split(K, s)
+
+
+def test_auto_split_is_always_accepted():
+    lib = L.lib()
+    for M, N in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (768, 768), (256, 256), (3072, 768), (128, 96)]:
+        for K in [31, 64, 200, 256, 1000, 4096, 6276 * 8, 18848, 100000]:
+            for dtype in (L.XP_BF16, L.XP_F32):
+                s = lib.xp_gemm_auto_split(C.byref(_desc(M, N, K, dtype=dtype)))
+                assert s >= 1
+                ke = 64 if dtype == L.XP_BF16 else 32
+                assert s == 1 or _valid_split(K, s, ke) or _valid_split(K, s, 64), (M, N, K, dtype, s)
+
+
+def test_fused_colsum_availability():
+    lib = L.lib()
+    big = dict(a_ks=False, b_ks=True, out=L.XP_BF16)
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_GELU_BWD, **big))) == 2 * 74
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, **big))) == 2 * 74
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(256, 2048, 512, epi=L.EPI_GELU_BWD, **big))) == 0          # text tower: 128 family
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_BIAS, **big))) == 0            # other epilogue
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, a_ks=False, b_ks=True, out=L.XP_F32))) == 0
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, split=2, **big))) == 0
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, dtype=L.XP_F32, **big))) == 0
+
+
+def test_partial_row_counts_and_workspaces():
+    lib = L.lib()
+    for rows in (1, 31, 256, 18848, 50208):
+        for cols in (64, 768, 2304, 3072):
+            n = lib.xp_colsum_partial_rows(rows, cols)
+            assert 1 <= n <= -(-rows // 32) and n >= -(-rows // 128)
+            assert lib.xp_colsum_workspace_bytes(rows, cols) >= (n + 32) * cols * 4
+        nb = lib.xp_layernorm_bwd_partial_rows(rows)
+        assert 1 <= nb <= 512
+        assert lib.xp_layernorm_bwd_workspace_bytes(rows, 768) >= nb * 3 * 768 * 4
+    segs = (L.XpReduceSeg * 3)()
+    for i, w in enumerate((768, 3072, 64)):
+        segs[i].width, segs[i].nrows, segs[i].stride = w, 100, w
+    assert lib.xp_reduce_rows_batch_workspace_bytes(segs, 3) >= 32 * (768 + 3072 + 64) * 4
+    # attention: forward partials / backward (delta + proxy partials) share one workspace
+    assert lib.xp_attn_workspace_bytes(L.ATTN_PROXY, 8, 12, 4, 12, 196) >= 8 * 12 * 2356 * 4
+    assert lib.xp_attn_workspace_bytes(L.ATTN_CAUSAL, 8, 8, 0, 1, 32) == 8 * 8 * 32 * 4
+    assert lib.xp_nce_loss_workspace_bytes(64, 512) >= 2 * 64 * 64 * 4
+    assert lib.xp_vsc_fc_loss_workspace_bytes(64, 512) >= 6 * 64 * 64 * 4
