@@ -256,7 +256,7 @@ def main():
                          "traffic": FC1_PMC_TRAFFIC_BYTES if rows == 18848 else None,
                          "traffic_unit": "bytes/launch", "algorithmic_bytes": (rows * 768 + 3072 * 768 + 2 * rows * 3072) * 2},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and W == 1:           # reported baseline, rank 0 of the single-GPU run only
             res["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(res), flush=True)
     if W > 1:
