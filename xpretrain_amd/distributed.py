@@ -127,7 +127,9 @@ class GradBucketReducer:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self._active else []
 
     def _make_bucket(self, ps):
-        b = dict(flat=None, params=list(ps), views=None, ready=0, work=None, n=sum(p.numel() for p in ps))
+        # `events`: one CUDA event per parameter, recorded on the stream its gradient was produced on (the text tower runs
+        # on a side stream): the stream that packs the bucket waits for all of them first
+        b = dict(flat=None, params=list(ps), views=None, ready=0, work=None, n=sum(p.numel() for p in ps), events={})
         for p in ps:
             self._bucket_of[id(p)] = b
         self.buckets.append(b)
@@ -144,6 +146,10 @@ class GradBucketReducer:
     def _launch(self, b):
         """pack the bucket (one multi-tensor copy; parameters without a gradient contribute zeros) and all-reduce."""
         self._ensure_flat(b)
+        if b["events"]:
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for ev in b["events"].values():
+                cur.wait_event(ev)
         src, dst = [], []
         for p, v in zip(b["params"], b["views"]):
             if p.grad is None:
@@ -159,6 +165,11 @@ class GradBucketReducer:
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
+        if p.is_cuda:                      # the hook runs on the stream autograd produced this gradient on
+            ev = b["events"].get(id(p))
+            if ev is None:
+                ev = b["events"][id(p)] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(p.device))
         b["ready"] += 1
         if b["ready"] == len(b["params"]) and b["work"] is None:
             self._launch(b)
