@@ -17,7 +17,6 @@ fixtures; ``tests/test_oracle_golden.py`` checks this restatement against them
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 

@@ -2,7 +2,6 @@
 """Micro-benchmarks of the individual HIP kernels at BASELINE cfg #2 shapes (B=8, T=12, 224^2, ViT-B/16).
 Run on the GPU box:  python tools/bench_kernels.py [gemm|ln|attn|all]  -> prints one line per kernel."""
 import sys
-import time
 
 import torch
 

@@ -12,7 +12,6 @@ Reference call sites are cited per class (paths relative to /root/reference/CLIP
 """
 from __future__ import annotations
 
-import math
 import weakref
 from typing import Optional, Tuple
 
