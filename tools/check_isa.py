@@ -1,11 +1,19 @@
 #!/usr/bin/env python
-"""Post-compile lint of the inline-asm LDS transpose reads (csrc/common.h::lds_read_tr16_async).
+"""Post-compile lints of the generated gfx950 code.
+
+(1) Packed-fp32 hazard (every file): no `v_pk_*_f32` may carry an `op_sel:[...]` modifier with a bit set, i.e. take the HIGH
+dword of a source pair for its LOW result half.  On MI355X that form returns a wrong low half in lanes 48..63 while another
+kernel's wave issues MFMAs on the same SIMD (measured: csrc/probe.hip::probe_pk_kernel under tools/race_repro.py; DESIGN.md
+6.3) -- a run-to-run difference that only shows when two streams share a CU.  Kernels where hipcc forms such operands are
+built with XP_NO_PK_F32 (csrc/common.h).
+
+(2) Inline-asm LDS transpose reads (csrc/common.h::lds_read_tr16_async), files named with --asm-reads:
 
 The asm `ds_read_b64_tr_b16` is invisible to hipcc's waitcnt bookkeeping, so the source places an explicit
 `s_waitcnt lgkmcnt(0)` before the first use of its result.  This script checks the GENERATED code: between every
 `ds_read_b64_tr_b16 v[a:b], ...` that came from inline asm (marked by the `;;#ASMSTART` / `;;#ASMEND` pair hipcc emits) and
 the next `s_waitcnt` that waits lgkmcnt(0), no instruction may mention v[a..b] as an operand.  Usage:
-    check_isa.py file.s [file2.s ...]      exit status 1 on a violation
+    check_isa.py file.s [...] [--asm-reads file.s [...]]      exit status 1 on a violation
 """
 import re
 import sys
@@ -21,6 +29,22 @@ def regs_of(text):
         else:
             out.update(range(int(m.group(2)), int(m.group(3)) + 1))
     return out
+
+
+PK_OPSEL = re.compile(r"^v_pk_[a-z0-9]+_f32\b.*\bop_sel:\[([01,]+)\]")
+
+
+def check_pk(path):
+    """lint (1): packed fp32 instructions whose low half selects a high source dword"""
+    bad = 0
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.split(";")[0].strip()
+        m = PK_OPSEL.match(line)
+        if m and "1" in m.group(1):
+            print(f"{path}:{ln}: `{line}`: packed fp32 with op_sel low-half redirection (gfx950 MFMA co-issue hazard); "
+                  "mark the kernel XP_NO_PK_F32")
+            bad += 1
+    return bad
 
 
 def check(path):
@@ -58,6 +82,11 @@ def check(path):
 
 
 if __name__ == "__main__":
-    total = sum(check(p) for p in sys.argv[1:])
-    print(f"check_isa: {len(sys.argv) - 1} file(s), {total} violation(s)")
+    args = sys.argv[1:]
+    asm_reads = []
+    if "--asm-reads" in args:
+        i = args.index("--asm-reads")
+        asm_reads, args = args[i + 1:], args[:i]
+    total = sum(check_pk(p) for p in args + asm_reads) + sum(check(p) for p in asm_reads)
+    print(f"check_isa: {len(args) + len(asm_reads)} file(s), {total} violation(s)")
     sys.exit(1 if total else 0)

@@ -81,6 +81,19 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
   return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
+// ------------------------------------------------------------------------------------------ gfx950 packed-fp32 hazard
+// Measured on MI355X (tools/race_repro.py, csrc/probe.hip::probe_pk_kernel): a `v_pk_add_f32` whose LOW
+// result half takes the HIGH dword of a source pair (`op_sel:[0,1]`, the form hipcc emits for `x - m[1]` when it keeps two
+// row scalars {m0, m1} in one register pair) returns a wrong low half in lanes 48..63 while a wave of ANOTHER kernel issues
+// MFMAs on the same SIMD (kernels of two streams sharing a CU).  Alone on the GPU the instruction is exact, so single-stream
+// tests never see it.  Kernels in which hipcc forms such operands are compiled without packed fp32 arithmetic (they are
+// HBM- or latency-bound), and the build lints the generated code of every kernel for the form (tools/check_isa.py).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XP_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define XP_NO_PK_F32
+#endif
+
 // ------------------------------------------------------------------------------------------ wave ops
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -70,7 +70,7 @@ __device__ __forceinline__ f32x4 cvt4(bf16x4 v) { return f32x4{(float)v[0], (flo
 // DXS: also accumulate the column sums of the dx this kernel writes (the bias gradient of the Linear whose output feeds
 // the residual stream here); the partial rows are then [dgamma | dbeta | dxsum].
 template <typename T, int NJ, bool DXS>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* dres, int64_t lddres,
                                                      T* dx, int64_t lddx, float* __restrict__ part,

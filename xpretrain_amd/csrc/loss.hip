@@ -10,7 +10,7 @@
 namespace {
 
 // C[i][j] = alpha * sum_k X(i,k) Y(k,j), generic strides; 32x32 tile, 256 threads, 2x2 per thread.
-__global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restrict__ X, int64_t sxi, int64_t sxk,
+__global__ __launch_bounds__(256) XP_NO_PK_F32 void sgemm_strided_kernel(const float* __restrict__ X, int64_t sxi, int64_t sxk,
                                                             const float* __restrict__ Y, int64_t syk, int64_t syj,
                                                             float* __restrict__ C, int64_t ldc, int I, int J, int K,
                                                             const float* __restrict__ log_scale, int accumulate = 0) {

@@ -28,7 +28,78 @@ __global__ void probe_tr16_kernel(const unsigned short* in, const int* off, i16x
   out[l] = lds_read_tr16(reinterpret_cast<const char*>(lds) + off[l]);
 }
 
+// Packed-fp32 probe (determinism hunt): every wave repeats one packed-fp32 instruction form and compares
+// both halves with the same arithmetic done by unpacked VALU instructions; err[(variant * 64 + lane) * 2 + half] counts
+// the mismatches.  Run beside an MFMA kernel on another stream it tells a hardware interaction from a compiler problem.
+//   0: v_pk_add_f32 x, m                      1: ... op_sel_hi:[1,0]            2: ... neg_lo:[0,1] neg_hi:[0,1]
+//   3: ... op_sel_hi:[1,0] neg (x - m.lo)     4: ... op_sel:[0,1] neg (x - m.hi) 5: v_pk_mul_f32 op_sel_hi:[1,0]
+//   6: v_pk_fma_f32 x, m, x                   7: v_pk_mul_f32 x, m
+//   8: v_pk_add_f32 op_sel:[0,1] (no neg)     9: v_pk_mul_f32 op_sel:[0,1]      10: v_pk_fma_f32 x, m, x op_sel:[1,0,0]
+//  11: v_pk_add_f32 op_sel:[1,0]             12: v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (halves of m swapped)
+//  13: v_pk_mul_f32 op_sel_hi:[0,1]
+constexpr int PK_VARIANTS = 14;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <int V>
+__device__ __forceinline__ void pk_variant(f32x2 x, f32x2 m, f32x2& r, float& e0, float& e1) {
+  if constexpr (V == 0) { asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 1) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %4" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 2) { asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 3) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %4" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 4) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_sub_f32 %0, %2, %5\n\tv_sub_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 5) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 6) { asm volatile("v_pk_fma_f32 %0, %1, %2, %1" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_fma_f32 %0, %2, %4, %2\n\tv_fma_f32 %1, %3, %5, %3" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 7) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 8) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_add_f32 %0, %2, %5\n\tv_add_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 9) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_mul_f32 %0, %2, %5\n\tv_mul_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 10) { asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_fma_f32 %0, %3, %4, %2\n\tv_fma_f32 %1, %3, %5, %3" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 11) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_add_f32 %0, %3, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 12) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_add_f32 %0, %2, %5\n\tv_add_f32 %1, %3, %4" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 13) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %2, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+}
+template <int V>
+__device__ __forceinline__ void pk_run(unsigned* err, int iters, unsigned s, int lane) {
+  unsigned e_lo = 0, e_hi = 0;
+  for (int i = 0; i < iters; ++i) {
+    s = s * 1664525u + 1013904223u;
+    const f32x2 x = {__uint_as_float(0x3f000000u | (s >> 9)), __uint_as_float(0x3f000000u | ((s * 7u) >> 9))};
+    const f32x2 m = {__uint_as_float(0x3d000000u | ((s * 13u) >> 9)), __uint_as_float(0x3d000000u | ((s * 29u) >> 9))};
+    f32x2 r; float e0, e1;
+    pk_variant<V>(x, m, r, e0, e1);
+    e_lo += r[0] != e0; e_hi += r[1] != e1;
+  }
+  if (e_lo) atomicAdd(err + (V * 64 + lane) * 2, e_lo);
+  if (e_hi) atomicAdd(err + (V * 64 + lane) * 2 + 1, e_hi);
+}
+__global__ __launch_bounds__(256) void probe_pk_kernel(unsigned* err, int iters, unsigned seed) {
+  const int lane = threadIdx.x & 63;
+  const unsigned s = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+  pk_run<0>(err, iters, s, lane); pk_run<1>(err, iters, s + 1, lane); pk_run<2>(err, iters, s + 2, lane); pk_run<3>(err, iters, s + 3, lane);
+  pk_run<4>(err, iters, s + 4, lane); pk_run<5>(err, iters, s + 5, lane); pk_run<6>(err, iters, s + 6, lane); pk_run<7>(err, iters, s + 7, lane);
+  pk_run<8>(err, iters, s + 8, lane); pk_run<9>(err, iters, s + 9, lane); pk_run<10>(err, iters, s + 10, lane); pk_run<11>(err, iters, s + 11, lane);
+  pk_run<12>(err, iters, s + 12, lane); pk_run<13>(err, iters, s + 13, lane);
+}
+
 }  // namespace
+
+extern "C" int xp_probe_pk_f32(void* err, int32_t iters, int32_t blocks, uint32_t seed, void* stream) {
+  probe_pk_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((unsigned*)err, iters, seed);
+  XP_CHECK_LAUNCH("xp_probe_pk_f32");
+  return XP_OK;
+}
 
 extern "C" int xp_probe_mfma_bf16(const void* a, const void* b, float* c, void* stream) {
   probe_mfma_bf16_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const bf16x8*)a, (const bf16x8*)b, (f32x4*)c);
