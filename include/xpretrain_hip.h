@@ -186,7 +186,8 @@ int xp_vip_embed_bwd(const void* dx, float* d_class, float* d_added, float* d_po
 /* CLIPTextEmbeddings.forward (:210-227): x[b,t] = tok[ids[b,t]] + pos[t] */
 int xp_text_embed_fwd(const int64_t* ids, const float* tok, const float* pos, void* x,
                       int64_t B, int64_t Lt, int64_t D, int64_t vocab, int32_t dtype, void* stream);
-/* d_tok[ids[b,t]] += dx[b,t] (atomic fp32); d_pos[t] (+)= sum_b dx[b,t] */
+/* d_tok[id] (+)= sum of dx[b,t] over the occurrences of id in (b,t) order (fixed order, no atomics: bit-reproducible);
+ * d_pos[t] (+)= sum_b dx[b,t] */
 int xp_text_embed_bwd(const int64_t* ids, const void* dx, float* d_tok, float* d_pos,
                       int64_t B, int64_t Lt, int64_t D, int64_t vocab, int32_t dtype, int32_t accumulate, void* stream);
 /* pooled[b] = x[b, idx[b]] (text: idx = ids.argmax(-1), :776 ; vision: idx = 0, :892) and its scatter */

@@ -1,9 +1,9 @@
 """GPU: BASELINE config #2 at FULL size (ViT-B/16, 12 frames 224^2, 32 text tokens, batch 8) -- the oracle takes minutes
 there, so the step is checked through size-independent properties:
 
-* run-to-run determinism: features, loss and every parameter gradient are bit-identical (fixed-order reductions) -- with ONE
-  exception: the token-embedding gradient is an fp32 atomic scatter (xp_text_embed_bwd), and the EOT token that pads
-  every caption receives ~100 contributions whose order is not fixed; it is compared to 1e-6 of its max instead;
+* run-to-run determinism: features, loss and EVERY parameter gradient are bit-identical over several repetitions with the
+  text tower overlapping the video tower on its side stream (fixed-order reductions everywhere, no atomics; the gfx950
+  packed-fp32 hazard that broke this in round 1 is described in DESIGN.md 6.3 / tests/test_determinism_gpu.py);
 * batch-permutation equivariance, bit-exact: every kernel treats samples independently and a row's accumulation order
   does not depend on where its tile sits;
 * unit-norm features; the fused loss kernel equals the oracle's loss formula evaluated on the same (GPU) features;
@@ -41,13 +41,11 @@ def test_cfg2_full_size_properties():
     loss_fn = NCELearnableTempLoss()
 
     v1, t1, l1, g1 = _run(model, loss_fn, video, ids, mask)
-    v2, t2, l2, g2 = _run(model, loss_fn, video, ids, mask)
-    assert torch.equal(v1, v2) and torch.equal(t1, t2) and torch.equal(l1, l2), "forward is not deterministic"
-    for n in g1:
-        if n.endswith("token_embedding.weight"):      # atomic scatter: order of the duplicate-token adds is not fixed
-            assert (g1[n] - g2[n]).abs().max().item() <= 1e-6 * g1[n].abs().max().item(), n
-        else:
-            assert torch.equal(g1[n], g2[n]), f"gradient of {n} is not deterministic"
+    for rep in range(8):
+        v2, t2, l2, g2 = _run(model, loss_fn, video, ids, mask)
+        assert torch.equal(v1, v2) and torch.equal(t1, t2) and torch.equal(l1, l2), "forward is not deterministic"
+        bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+        assert not bad, f"repetition {rep}: gradients not bit-identical: {bad[:5]} ({len(bad)} of {len(g1)})"
 
     perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4], device="cuda")
     with torch.no_grad():

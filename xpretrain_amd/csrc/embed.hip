@@ -127,18 +127,45 @@ __global__ void text_embed_fwd_kernel(const int64_t* __restrict__ ids, const flo
     store4(x + r * D + d, load4(tok + ids[r] * D + d) + load4(pos + (int64_t)t * D + d));
   }
 }
+// Token-table gradient without atomics: one workgroup per token occurrence r; only the FIRST occurrence of a token id
+// works, and adds the dx rows of all its occurrences in row order (fixed order -> bit-reproducible; the EOT id that pads
+// every caption has ~100 occurrences).  Occurrences are found 256 rows at a time (one compare per thread, ballot per
+// wave), then every thread walks the set bits of the four masks in order.
 template <typename T>
-__global__ void text_embed_bwd_tok_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx, float* d_tok,
-                                          int64_t rows, int D) {
+__global__ __launch_bounds__(256) void text_embed_bwd_tok_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx,
+                                                                 float* d_tok, int64_t rows, int D, int acc) {
+  __shared__ unsigned long long masks[4];
+  const int64_t r = blockIdx.x, id = ids[r];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int earlier = 0;
+  for (int64_t q = threadIdx.x; q < r; q += 256) earlier |= ids[q] == id;
+  if (__syncthreads_or(earlier)) return;                       // block-uniform
   const int D4 = D / 4;
-  const int64_t total = rows * D4;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int d = (int)(idx % D4) * 4;
-    const int64_t r = idx / D4;
-    const f32x4 g = load4(dx + r * D + d);
-    float* o = d_tok + ids[r] * D + d;
+  for (int d40 = 0; d40 < D4; d40 += 256) {
+    const int d = (d40 + threadIdx.x) * 4;
+    const bool ok = d < D;
+    f32x4 s = ok ? load4(dx + r * D + d) : f32x4{0, 0, 0, 0};
+    for (int64_t base = r + 1; base < rows; base += 256) {
+      const int64_t q = base + threadIdx.x;
+      const unsigned long long m = __ballot(q < rows && ids[q] == id);
+      __syncthreads();                                          // previous chunk's masks are consumed
+      if (lane == 0) masks[wave] = m;
+      __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(o + e, g[e]);
+      for (int w = 0; w < 4; ++w) {
+        unsigned long long mm = masks[w];
+        while (mm) {
+          const int j = __builtin_ctzll(mm);
+          mm &= mm - 1;
+          if (ok) s += load4(dx + (base + w * 64 + j) * D + d);
+        }
+      }
+    }
+    if (ok) {
+      float* o = d_tok + id * D + d;
+      if (acc) s += load4(o);
+      store4(o, s);
+    }
   }
 }
 template <typename T>
@@ -335,9 +362,9 @@ extern "C" int xp_text_embed_bwd(const int64_t* ids, const void* dx, float* d_to
     hipError_t e = hipMemsetAsync(d_tok, 0, (size_t)vocab * D * sizeof(float), st);
     XP_REQUIRE(e == hipSuccess, "xp_text_embed_bwd: memset failed: %s", hipGetErrorString(e));
   }
-  const int g = grid_for(B * Lt * D / 4);
-  DISPATCH(dtype, (text_embed_bwd_tok_kernel<bf16_t><<<g, TPB, 0, st>>>(ids, (const bf16_t*)dx, d_tok, B * Lt, (int)D)),
-           (text_embed_bwd_tok_kernel<float><<<g, TPB, 0, st>>>(ids, (const float*)dx, d_tok, B * Lt, (int)D)), "xp_text_embed_bwd");
+  const unsigned g = (unsigned)(B * Lt);            // one workgroup per token occurrence (fixed-order sums, no atomics)
+  DISPATCH(dtype, (text_embed_bwd_tok_kernel<bf16_t><<<g, 256, 0, st>>>(ids, (const bf16_t*)dx, d_tok, B * Lt, (int)D, accumulate)),
+           (text_embed_bwd_tok_kernel<float><<<g, 256, 0, st>>>(ids, (const float*)dx, d_tok, B * Lt, (int)D, accumulate)), "xp_text_embed_bwd");
   XP_CHECK_LAUNCH("xp_text_embed_bwd(tok)");
   const int g2 = grid_for(Lt * D / 4);
   DISPATCH(dtype, (text_embed_bwd_pos_kernel<bf16_t><<<g2, TPB, 0, st>>>((const bf16_t*)dx, d_pos, B, (int)Lt, (int)D, accumulate)),
