@@ -26,15 +26,36 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+class _RoundBoth(torch.autograd.Function):
+    """value AND incoming gradient rounded to the storage dtype (the HIP path keeps the gradient of every bf16 activation in
+    bf16 as well: residual-stream, LayerNorm-output, q/k/v, attention-output and MLP gradients)."""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        ctx.dtype = dtype
+        return t.to(dtype).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
 class _Rounding:
     """Optional storage-precision emulation.  With ``ROUND.dtype = torch.bfloat16`` every tensor the HIP path
     stores in bf16 (weights fed to GEMMs, LayerNorm outputs, q/k/v, attention output, softmax probabilities fed
     to P.V, MLP pre-activation/activation, the residual stream) is rounded at the same point here, so a kernel
-    can be told apart from bf16 noise: HIP-vs-emulation must agree far tighter than HIP-vs-fp32.  Default: off."""
+    can be told apart from bf16 noise: HIP-vs-emulation must agree far tighter than HIP-vs-fp32.  With
+    ``ROUND.grads = True`` the gradients of the rounded ACTIVATIONS are rounded too (weights: ``grad=False`` -- parameter
+    gradients are fp32 in the HIP path), which makes the emulation a tight reference for the backward.  Default: off."""
     dtype = None
+    grads = False
 
-    def __call__(self, t: Tensor) -> Tensor:
-        return t if self.dtype is None else t.to(self.dtype).to(t.dtype)
+    def __call__(self, t: Tensor, grad: bool = True) -> Tensor:
+        if self.dtype is None:
+            return t
+        if self.grads and grad and t.requires_grad:
+            return _RoundBoth.apply(t, self.dtype)
+        return t.to(self.dtype).to(t.dtype)
 
 
 ROUND = _Rounding()
@@ -84,7 +105,7 @@ def quick_gelu(x: Tensor) -> Tensor:
 
 
 def linear(x: Tensor, sd: Dict[str, Tensor], name: str, bias: bool = True) -> Tensor:
-    y = x @ ROUND(sd[name + ".weight"]).t()
+    y = x @ ROUND(sd[name + ".weight"], grad=False).t()
     if bias:
         y = y + sd[name + ".bias"]
     return y
@@ -206,7 +227,7 @@ def vip_embeddings(video: Tensor, sd: Dict[str, Tensor], cfg: OracleCfg):
     wconv = sd["vision_model.embeddings.patch_embedding.weight"]      # [D,3,P,P]
     D = wconv.shape[0]
     patches = ROUND(video.reshape(B, T, C, gh, P, gw, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, gh * gw, C * P * P))
-    pe = patches @ ROUND(wconv.reshape(D, -1)).t()                    # [B,T,L,D]
+    pe = patches @ ROUND(wconv.reshape(D, -1), grad=False).t()                    # [B,T,L,D]
     pos = sd["vision_model.embeddings.position_embedding.weight"]     # [1+L,D]
     if cfg.use_temporal_embed:
         pe = pe + temporal_table(sd, T)[None, :, None, :]
@@ -258,8 +279,8 @@ def clip_features(video: Tensor, ids: Tensor, mask: Optional[Tensor], sd: Dict[s
     CLIP_ViP.py:1125-1149).  Returns (vis_features, text_features), unit-norm [B,proj]."""
     _, vp = vision_tower(video, sd, cfg)
     _, tp = text_tower(ids, mask, sd, cfg)
-    vis = l2_normalize(ROUND(vp @ ROUND(sd["visual_projection.weight"]).t()))
-    txt = l2_normalize(ROUND(tp @ ROUND(sd["text_projection.weight"]).t()))
+    vis = l2_normalize(ROUND(vp @ ROUND(sd["visual_projection.weight"], grad=False).t()))
+    txt = l2_normalize(ROUND(tp @ ROUND(sd["text_projection.weight"], grad=False).t()))
     return vis, txt
 
 

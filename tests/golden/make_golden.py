@@ -21,6 +21,12 @@ Fixtures (all fp32, CPU, torch.manual_seed'ed):
                      and logit scales (incl. both clamp limits 0 and ln 200).
   retrieval.pt       src/utils/metrics.py (cal_cossim, np_softmax, compute_metrics, compute_metrics_multi) in the simple
                      and DSL settings of validate(), incl. exact score ties; ImageNorm arithmetic on uint8 frames.
+  full_cfg2.pt, full_cfg3.pt, full_cfg4.pt
+                     BASELINE configs[1], [3], [4] at FULL model size (ViT-B/16; 12x224^2 / 8x448^2 / 32x224^2, 32 text
+                     tokens) and batch 2 through the reference VidCLIP.forward + NCELearnableTempLoss + backward, weights
+                     rebuilt from seeds (tests/gpu_util.py::seeded_model): features, loss, sampled rows of every hidden
+                     state, every 1-D gradient, three rows of every weight gradient.  (Batch 2: at batch 1 the contrastive
+                     loss is identically 0.)
   optim.pt           src/optimization: AdamW.step x 6 with clip_grad_norm_ 5.0 and the warmup-cosine schedule
                      over the four build_e2e_optimizer_w_lr_mul groups; get_lr_sched tables.
 """
@@ -93,6 +99,58 @@ def tiny_e2e(ref):
     )
     torch.save(fx, os.path.join(HERE, "tiny_e2e.pt"))
     print("tiny_e2e: loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
+
+
+def full_size(ref, name, frames, res, B=2, txt_len=32, patch=16, temporal_size=12):
+    """One full-size case; what is kept is small (see the module docstring).  Uses this repo's model class only to BUILD
+    the seeded weights -- the numbers stored come from the reference."""
+    from tests.gpu_util import seeded_model, sample_rows
+    cfgd = O.vit_b_config(patch, res)
+    ours = seeded_model(cfgd, temporal_size)
+    args = ref_import.make_args(cfgd, add_cls_num=3, temporal_size=temporal_size)
+    model = ref.VidCLIP.VidCLIP(args)
+    model.load_state_dict(ours.state_dict(), strict=True)
+    del ours
+    model.train()
+    video, ids, mask = O.synthetic_inputs(B, frames, res, txt_len)
+    out = model(video, ids, mask)
+    loss = ref.loss.NCELearnableTempLoss(None)(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+    loss.backward()
+    with torch.no_grad():
+        vo = model.clipmodel.vision_model(pixel_values=video, output_hidden_states=True, return_dict=True)
+        to = model.clipmodel.text_model(input_ids=ids, attention_mask=mask, output_hidden_states=True, return_dict=True)
+        # calibration: the reference's OWN reduced-precision path on the same input -- torch.autocast(bfloat16) (pure
+        # .bfloat16() fails in its text tower, SURVEY 8a defect 2).  How far bf16 matmul inputs alone move features, logits
+        # and loss away from the fp32 run is what "2e-2 bf16" can mean at logit scale e^4.6 ~ 100.
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ob = model(video, ids, mask)
+        bv, bt = ob["vis_features"].float(), ob["text_features"].float()
+        sc = model.clipmodel.logit_scale.exp()
+        ref_bf16 = dict(loss=ref.loss.NCELearnableTempLoss(None)(bv, bt, model.clipmodel.logit_scale).item(),
+                        dvis=(bv - out["vis_features"]).abs().max().item(), dtxt=(bt - out["text_features"]).abs().max().item(),
+                        dlogits=((bv @ bt.t() - out["vis_features"] @ out["text_features"].t()) * sc).abs().max().item())
+    L = (res // patch) ** 2
+    S = 4 + frames * L
+    rows = sample_rows(S, 4)
+    grads = {}
+    for n, p in model.named_parameters():
+        g = p.grad.detach()
+        if g.dim() <= 1 or g.numel() <= 4096 * 4:
+            grads[n] = g.clone()
+        elif n.endswith("token_embedding.weight"):
+            grads[n + "#rows"] = (ids.unique(), g[ids.unique()].clone())
+        else:
+            g2 = g.reshape(g.shape[0], -1)
+            pick = torch.tensor([0, g2.shape[0] // 2, g2.shape[0] - 1])
+            grads[n + "#rows"] = (pick, g2[pick].clone())
+    fx = dict(patch=patch, frames=frames, res=res, B=B, txt_len=txt_len, temporal_size=temporal_size, rows=rows,
+              vis_features=out["vis_features"].detach(), text_features=out["text_features"].detach(), loss=loss.detach(),
+              vision_hidden=[h[:, rows].detach().half() for h in vo.hidden_states],
+              text_hidden=[h.detach().half() for h in to.hidden_states],
+              vision_pooled=vo.pooler_output.detach(), text_pooled=to.pooler_output.detach(), grads=grads, ref_bf16=ref_bf16)
+    torch.save(fx, os.path.join(HERE, name))
+    print(name, "reference bf16 autocast vs fp32:", ref_bf16)
+    print(name, "loss", float(loss), "size MB", os.path.getsize(os.path.join(HERE, name)) / 1e6)
 
 
 def _attn_module(ref, D, H, seed):
@@ -281,6 +339,11 @@ if __name__ == "__main__":
     ref = ref_import.load()
     if len(sys.argv) > 1 and sys.argv[1] in ("optim", "retrieval"):
         {"optim": optim, "retrieval": retrieval}[sys.argv[1]](ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full":        # minutes of CPU time each; not part of the default regeneration
+        for nm, fr, rs in (("full_cfg2.pt", 12, 224), ("full_cfg3.pt", 8, 448), ("full_cfg4.pt", 32, 224)):
+            if len(sys.argv) < 3 or sys.argv[2] in nm:
+                full_size(ref, nm, fr, rs)
         sys.exit(0)
     tiny_e2e(ref)
     attn_forward2(ref)

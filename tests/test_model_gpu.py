@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import clipvip_oracle as O
-from tests.gpu_util import report
+from tests.gpu_util import TOL, report
 
 pytestmark = pytest.mark.gpu
 
@@ -67,8 +67,20 @@ def test_tiny_e2e_against_reference_fixture(golden):
     assert not bad, bad
 
 
+def _oracle_step(model, video, ids, mask, cfg, emulate):
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
+    O.ROUND.dtype, O.ROUND.grads = (torch.bfloat16, True) if emulate else (None, False)
+    try:
+        loss, vis, txt = O.full_step(video, ids, mask, sd, cfg)
+        loss.backward()
+    finally:
+        O.ROUND.dtype, O.ROUND.grads = None, False
+    return loss.detach(), vis.detach(), txt.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+
 def test_cfg1_architecture_against_oracle():
-    """BASELINE config #1: ViT-B/32, 2 frames 224^2, 16 text tokens, batch 2."""
+    """BASELINE config #1: ViT-B/32, 2 frames 224^2, 16 text tokens, batch 2 -- features, loss and EVERY parameter gradient
+    against the oracle in fp32 and with bf16 storage emulation (tolerances: tests/gpu_util.py::TOL)."""
     from xpretrain_amd.modeling import VidCLIP
     from xpretrain_amd.optimization import NCELearnableTempLoss
     torch.manual_seed(1234)
@@ -77,32 +89,32 @@ def test_cfg1_architecture_against_oracle():
     with torch.no_grad():
         model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.02)
     video, ids, mask = O.synthetic_inputs(2, 2, 224, 16)
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
-    ref_loss, ref_vis, ref_txt = O.full_step(video, ids, mask, sd, O.OracleCfg.from_hf_dict(cfgd))
-    ref_loss.backward()
+    cfg = O.OracleCfg.from_hf_dict(cfgd)
+    ref_loss, ref_vis, ref_txt, ref_g = _oracle_step(model, video, ids, mask, cfg, emulate=False)
+    emu_loss, emu_vis, emu_txt, emu_g = _oracle_step(model, video, ids, mask, cfg, emulate=True)
     model.cuda().train()
     out = model(video.cuda(), ids.cuda(), mask.cuda())
     loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
     loss.backward()
     dv = (out["vis_features"].cpu() - ref_vis).abs().max().item()
     dt = (out["text_features"].cpu() - ref_txt).abs().max().item()
-    print(f"cfg1: loss {loss.item():.6f} oracle {ref_loss.item():.6f} dvis {dv:.2e} dtxt {dt:.2e}")
-    assert dv < 2e-2 and dt < 2e-2
-    assert abs(loss.item() - ref_loss.item()) < 2e-2
-    # Weight gradients: 8e-2 of the tensor's max.  1-D gradients (biases, LayerNorm affine) of the 32-token text tower
-    # are sums of 32 signed bf16-rounded rows that largely cancel, so the same absolute bf16 noise is a larger fraction
-    # of their max: measured 2e-2 .. 1.0e-1 over builds that differ only in rounding (e.g. v_rcp vs IEEE divide in
-    # quick_gelu) -- 1.5e-1 for those.
-    worst_w, worst_v = 0.0, 0.0
+    print(f"cfg1: loss {loss.item():.6f} oracle fp32 {ref_loss.item():.6f} emulation {emu_loss.item():.6f} dvis {dv:.2e} dtxt {dt:.2e}")
+    assert dv <= TOL["features_abs"] and dt <= TOL["features_abs"]
+    assert abs(loss.item() - ref_loss.item()) <= TOL["loss_ref_abs"]
+    # The free-running emulation is reported, not gated: two bf16 realisations of a 12-layer network are as far from each
+    # other as from fp32; the tight emulation gates are the teacher-forced per-layer ones of test_fullsize_parity_gpu.py.
+    worst = {"grad_ref_2d": 0.0, "grad_ref_1d": 0.0}
+    info = {"grad_emu": 0.0}
     for name, p in model.named_parameters():
-        ref = sd[name[len("clipmodel."):]].grad
-        assert p.grad is not None and ref is not None, name
-        if ref.abs().max() > 1e-5:
-            if p.dim() >= 2:
-                worst_w = max(worst_w, report(f"cfg1 grad {name}", p.grad, ref, 8e-2))
-            else:
-                worst_v = max(worst_v, report(f"cfg1 grad {name}", p.grad, ref, 1.5e-1))
-    assert worst_w <= 8e-2 and worst_v <= 1.5e-1
+        key = name[len("clipmodel."):]
+        assert p.grad is not None and key in ref_g, name
+        if ref_g[key].abs().max() <= 1e-5:
+            continue
+        k_ref = "grad_ref_2d" if p.dim() >= 2 else "grad_ref_1d"
+        worst[k_ref] = max(worst[k_ref], report(f"cfg1 grad {name} vs fp32 oracle", p.grad, ref_g[key], TOL[k_ref]))
+        info["grad_emu"] = max(info["grad_emu"], report(f"cfg1 grad {name} vs free-running emulation (info)", p.grad, emu_g[key], 1.0))
+    print("cfg1 worst gradient errors", worst, info)
+    assert all(worst[k] <= TOL[k] for k in worst), worst
 
 
 def test_second_pass_T1_interpolated_temporal_embedding():

@@ -138,3 +138,38 @@ def test_live_reference_cfg1_shape():
     torch.testing.assert_close(vis, out["vis_features"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(txt, out["text_features"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(l2, loss, rtol=1e-4, atol=1e-4)
+
+
+def test_oracle_matches_reference_at_full_size_cfg2(golden):
+    """The restatement against the unmodified reference at BASELINE configs[1]'s full model size (ViT-B/16, 12 frames 224^2,
+    32 text tokens, batch 2; tests/golden/full_cfg2.pt): features, loss, sampled hidden-state rows and gradients, fp32."""
+    from tests.gpu_util import seeded_model
+    fx = golden("full_cfg2.pt")
+    cfgd = O.vit_b_config(fx["patch"], fx["res"])
+    model = seeded_model(cfgd, fx["temporal_size"])
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in O.strip_prefix(model.state_dict()).items()}
+    del model
+    video, ids, mask = O.synthetic_inputs(fx["B"], fx["frames"], fx["res"], fx["txt_len"])
+    cfg = O.OracleCfg.from_hf_dict(cfgd, temporal_size=fx["temporal_size"])
+    vh = []
+    _, vp = O.vision_tower(video, sd, cfg, collect=vh)
+    _, tp = O.text_tower(ids, mask, sd, cfg)
+    vis = O.l2_normalize(vp @ sd["visual_projection.weight"].t())
+    txt = O.l2_normalize(tp @ sd["text_projection.weight"].t())
+    loss = O.nce_learnable_temp_loss(vis, txt, sd["logit_scale"])
+    loss.backward()
+    assert (vis - fx["vis_features"]).abs().max() < 2e-5 and (txt - fx["text_features"]).abs().max() < 2e-5
+    assert abs(loss.item() - fx["loss"].item()) < 1e-4
+    for h, r in zip(vh[1:], fx["vision_hidden"]):          # fixture rows are stored in fp16
+        assert (h[:, fx["rows"]].detach() - r.float()).abs().max() <= 2e-3 * max(1.0, r.float().abs().max().item())
+    for key, ref in fx["grads"].items():
+        if key.endswith("#rows"):
+            pick, ref = ref
+            g = sd[key[len("clipmodel."):-5]].grad
+            g = g.reshape(g.shape[0], -1)[pick]
+        else:
+            g = sd[key[len("clipmodel."):]].grad
+        scale = ref.abs().max().item()
+        if scale < 1e-7:          # k_proj.bias: mathematically zero (softmax is shift-invariant), pure rounding noise
+            continue
+        assert (g - ref).abs().max().item() <= 2e-3 * scale, key
