@@ -47,6 +47,33 @@ def _worker(rank, world, port, q):
     ok = (torch.allclose(loss, ref, atol=1e-6)
           and torch.allclose(Wv.grad, Wv2.grad / world, atol=1e-6) and torch.allclose(Wt.grad, Wt2.grad / world, atol=1e-6)
           and torch.allclose(ls.grad, ls2.grad, atol=1e-6))
+    # gradient accumulation (run_pretrain.py:373-382): first micro-step under no_sync, second one reduces the SUM of both
+    single = [p.grad.clone() for p in (Wv, Wt, ls)]
+    red.zero_grad()
+
+    def micro():
+        vis = torch.nn.functional.normalize(xv @ Wv, dim=-1); txt = torch.nn.functional.normalize(xt @ Wt, dim=-1)
+        gv, gt = D.gather_features(vis, txt)
+        O.nce_learnable_temp_loss(gv, gt, ls).backward()
+    with red.no_sync():
+        micro()
+    micro()
+    red.synchronize()
+    ok = ok and all(torch.allclose(p.grad, 2 * g, atol=1e-6) for p, g in zip((Wv, Wt, ls), single))
+    # a second un-guarded backward before synchronize() must raise, not silently drop its contribution
+    red.zero_grad()
+    micro()
+    try:
+        micro()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "no_sync" in str(e)
+    red.synchronize()
+    # four features in one collective (the pre-training step, run_pretrain.py:344-353)
+    f4 = [torch.full((B, 4), float(rank * 10 + i)) for i in range(4)]
+    g4 = D.gather_packed(*f4)
+    ok = ok and len(g4) == 4 and all(g.shape == (world * B, 4) and float(g[r * B, 0]) == r * 10 + i
+                                     for i, g in enumerate(g4) for r in range(world))
     q.put((rank, bool(ok), float(loss), float(ref)))
     dist.barrier()
     dist.destroy_process_group()

@@ -201,3 +201,53 @@ def test_pretrain_step_dual_pass_vsc_fc_against_oracle():
         if ref.abs().max() > 1e-5:
             worst = max(worst, report(f"pretrain-step grad {name}", p.grad, ref, 8e-2))
     assert worst <= 8e-2
+
+
+def test_output_fields_frozen_text_tower_and_stale_weight_guard():
+    """(1) every output field of the reference is there (lazily computed ones too) and an unknown name raises;
+    (2) freeze_text_encoder (VidCLIP.py:96-103): the text tower's parameter-gradient kernels are skipped, the video tower's
+    gradients are bit-identical to the unfrozen run; (3) forward -> optimizer.step() -> backward fails loudly: the bf16
+    weight copies saved for backward were rewritten by the optimizer kernel."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import AdamW, NCELearnableTempLoss
+    torch.manual_seed(5)
+    cfgd = O.hf_config_dict(128, 2, 2, 256, 16, 32, 128, 2, 2, 256, 120, 16, 64)
+    model = VidCLIP(_Args(cfgd, 2)).cuda().train()
+    video, ids, mask = (t.cuda() for t in O.synthetic_inputs(3, 2, 32, 8, vocab=120))
+    sd = {k: v.detach().cpu() for k, v in O.strip_prefix(model.state_dict()).items()}
+    cfg = O.OracleCfg.from_hf_dict(cfgd, temporal_size=2)
+    # (1)
+    to = model.clipmodel.text_model(input_ids=ids, attention_mask=mask)
+    ref_last, _ = O.text_tower(ids.cpu(), mask.cpu(), sd, cfg)
+    assert to.last_hidden_state.shape == ref_last.shape
+    assert (to.last_hidden_state.float().cpu() - ref_last).abs().max() < 5e-2 * ref_last.abs().max()
+    out = model.clipmodel(input_ids=ids, pixel_values=video, attention_mask=mask)
+    want = out.text_embeds @ out.image_embeds.t() * model.clipmodel.logit_scale.exp()
+    assert torch.allclose(out.logits_per_text, want) and torch.allclose(out["logits_per_image"], want.T)
+    assert out.loss is None
+    with pytest.raises(AttributeError):
+        out.no_such_field
+    # (2)
+    loss_fn = NCELearnableTempLoss()
+
+    def grads():
+        for p in model.parameters():
+            p.grad = None
+        o = model(video, ids, mask)
+        loss_fn(o["vis_features"], o["text_features"], model.clipmodel.logit_scale).backward()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+    g_all = grads()
+    model.freeze_text_encoder(True)
+    g_frozen = grads()
+    for n, g in g_frozen.items():
+        if ".text_model." in n or "text_projection" in n:
+            assert g is None, n
+        else:
+            assert torch.equal(g, g_all[n]), n
+    # (3)
+    opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    o = model(video, ids, mask)
+    loss = loss_fn(o["vis_features"], o["text_features"], model.clipmodel.logit_scale)
+    opt.step()                      # rewrites the bf16 weight copies the graph above saved
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()

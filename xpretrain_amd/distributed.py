@@ -87,14 +87,20 @@ def allgather(x: torch.Tensor, verify_identical: bool = False) -> torch.Tensor:
     return _AllGatherRows.apply(x, verify_identical)
 
 
+def gather_packed(*feats: torch.Tensor, verify_identical: bool = False):
+    """k feature matrices [B,d] -> k gathered matrices [W*B,d] with ONE collective (rank-major rows, differentiable).
+    k = 2: the fine-tuning step (run_pretrain.py:344-345); k = 4: the pre-training step's video / subtitle / frame /
+    caption features (run_pretrain.py:344-353, four hvd.allgather calls in the reference)."""
+    if _single():
+        return feats
+    packed = torch.stack(feats, dim=1)                            # [B,k,d]: rows stay rank-major after the gather
+    g = _AllGatherRows.apply(packed, verify_identical)            # [W*B,k,d]
+    return tuple(g[:, i] for i in range(len(feats)))
+
+
 def gather_features(vis: torch.Tensor, txt: torch.Tensor, verify_identical: bool = False):
     """(vis[B,d], txt[B,d]) -> (vis[W*B,d], txt[W*B,d]) with ONE collective."""
-    if _single():
-        return vis, txt
-    B = vis.shape[0]
-    packed = torch.stack([vis, txt], dim=1)                       # [B,2,d]: rows stay rank-major after the gather
-    g = _AllGatherRows.apply(packed, verify_identical)            # [W*B,2,d]
-    return g[:, 0], g[:, 1]
+    return gather_packed(vis, txt, verify_identical=verify_identical)
 
 
 class GradBucketReducer:
@@ -104,7 +110,12 @@ class GradBucketReducer:
     per-parameter ``grad += new`` kernels, no zero-fill of 600 MB of gradient memory).  When the last gradient of
     a bucket arrives (autograd hook), the bucket's gradients are packed into its flat fp32 buffer with ONE
     multi-tensor copy, ``.grad`` is re-pointed at the flat views, and the bucket's all-reduce is launched
-    asynchronously -- overlapping the rest of backward.  With world_size 1 nothing is copied at all."""
+    asynchronously -- overlapping the rest of backward.  With world_size 1 nothing is copied at all.
+
+    Gradient accumulation (run_pretrain.py:373-382, ``skip_synchronize`` on all but the last micro-step): run the first
+    micro-steps under ``with reducer.no_sync():`` -- no hook counts, autograd accumulates into ``.grad`` as usual -- and
+    the last one outside it: the buckets then pack and reduce the accumulated gradients.  A second backward without
+    ``no_sync`` before ``synchronize()`` is an error (the in-flight collective would miss its contribution) and raises."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, average: bool = True,
                  group=None):
@@ -125,6 +136,22 @@ class GradBucketReducer:
         if cur:
             self._make_bucket(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self._active else []
+        self._sync = True
+        backend = dist.get_backend(group) if self._active else ""
+        self._avg_in_collective = average and backend == "nccl"      # RCCL divides inside the reduction; gloo has no AVG
+
+    def no_sync(self):
+        """context manager: backward passes inside it only accumulate into ``.grad`` (no packing, no collective)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = old
+        return ctx()
 
     def _make_bucket(self, ps):
         # `events`: one CUDA event per parameter, recorded on the stream its gradient was produced on (the text tower runs
@@ -159,12 +186,25 @@ class GradBucketReducer:
                 dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
+            if b["events"]:
+                # the sources may have been produced (and allocated) on another stream: re-pointing .grad below drops
+                # their last reference, and the caching allocator would hand the block back to the PRODUCER stream's pool
+                # at once -- where ongoing backward work could overwrite it while this copy is still queued
+                for g in src:
+                    g.record_stream(cur)
         for p, v in zip(b["params"], b["views"]):
             p.grad = v
-        b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
+        if not self._sync:
+            return
         b = self._bucket_of[id(p)]
+        if b["work"] is not None or b["ready"] >= len(b["params"]):
+            raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket whose all-reduce is already in flight -- "
+                               "run all but the last micro-step of a gradient-accumulation step under reducer.no_sync(), "
+                               "and call synchronize() + zero_grad() between optimizer steps")
         if p.is_cuda:                      # the hook runs on the stream autograd produced this gradient on
             ev = b["events"].get(id(p))
             if ev is None:
@@ -185,7 +225,7 @@ class GradBucketReducer:
         for b in self.buckets:
             b["work"].wait()
             b["work"] = None
-            if self.average:
+            if self.average and not self._avg_in_collective:
                 b["flat"].div_(W)
             b["ready"] = 0
 

@@ -68,6 +68,9 @@ class WeightCache:
                 ws = [r() for r in ent.refs]
                 if all(w is not None for w in ws):
                     ent.ver = self._ver(ws)
+                # the buffer was rewritten through a raw pointer: tell autograd, so that a graph which saved it for backward
+                # (forward -> optimizer.step() -> backward) fails loudly instead of computing dX with the new weights
+                torch.autograd.graph.increment_version(ent.buf)
 
     @staticmethod
     def _alive(ent, ws) -> bool:
@@ -93,6 +96,8 @@ class WeightCache:
             if not reuse:
                 self.structure_version += 1
             buf = ent.buf if reuse else torch.empty(shape, dtype=dtype, device=ws[0].device)
+            if reuse:
+                torch.autograd.graph.increment_version(buf)      # in-place rewrite below (raw pointer): see invalidate()
             if _single:
                 H.cast(ws[0].detach(), dtype, out=buf)
             else:
@@ -203,27 +208,40 @@ class EncoderLayerFn(torch.autograd.Function):
         defer = H.DeferredReduce(x.device)       # the 4 bias + 4 LayerNorm-parameter reductions finish in 2 launches
         # ---- MLP: x3 = x2 + fc2(quick_gelu(fc1(LN2(x2))))
         # fc1's bias gradient = column sums of dpre: taken from the epilogue of the GEMM that produces dpre
-        dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre, colsum_defer=defer)
-        dw2 = _wgrad(dx3, act, rows, D, Dff)
-        db2 = H.colsum_deferred(dx3, rows, D, defer)
+        # parameter gradients are skipped for frozen parameters (freeze_text_encoder, VidCLIP.py:96-103): positions in
+        # forward's argument list -- 1,2 ln1 | 3..8 q,k,v | 9,10 out_proj | 11,12 ln2 | 13,14 fc1 | 15,16 fc2
+        need = ctx.needs_input_grad
+        if need[14]:
+            dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre, colsum_defer=defer)
+        else:
+            dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre), None
+        dw2 = _wgrad(dx3, act, rows, D, Dff) if need[15] else None
+        db2 = H.colsum_deferred(dx3, rows, D, defer) if need[16] else None
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
-        dw1 = _wgrad(dpre, h2, rows, Dff, D)
+        dw1 = _wgrad(dpre, h2, rows, Dff, D) if need[13] else None
         # out_proj's bias gradient = column sums of dx2: accumulated by the LayerNorm backward that writes dx2
         dx2, dln2_w, dln2_b, dbo = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
                                                    dx_colsum=True)
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
-        dwo = _wgrad(dx2, attn_o, rows, D, D)
+        dwo = _wgrad(dx2, attn_o, rows, D, D) if need[9] else None
         dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
         dh1 = H.gemm(dqkv, Wqkv, rows, D, 3 * D, b_kstrided=True)
-        dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)
-        dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer)
+        if need[3] or need[5] or need[7]:
+            dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)
+            dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
+        else:
+            dwq = dwk = dwv = None
+        if need[4] or need[6] or need[8]:
+            dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer)
+            dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
+        else:
+            dbq = dbk = dbv = None
         dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer)
         defer.flush()
-        dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
-        dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
-        return (dx, dln1_w, dln1_b, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dln2_w, dln2_b, dw1, db1, dw2, db2,
-                None, None, None, None, None)
+        keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
+        return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),
+                keep(12, dln2_b), dw1, db1, dw2, db2, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ embeddings

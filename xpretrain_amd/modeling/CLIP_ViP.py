@@ -44,19 +44,51 @@ def _as_cfg(c):
     return _Cfg(c)
 
 
-class CLIPOutput(dict):
-    """dict with attribute access: loss, logits_per_image, logits_per_text, text_embeds, image_embeds,
-    text_model_output, vision_model_output (reference CLIPOutput, CLIP_ViP.py:76-111)."""
-    __getattr__ = dict.get
+class _Lazy:
+    """a field that is cheap but not free and that the training step never reads: computed on first access"""
+
+    def __init__(self, fn):
+        self.fn = fn
 
 
-class BaseModelOutputWithPooling(dict):
-    __getattr__ = dict.get
+class _Output(dict):
+    """dict with attribute access.  Every field of the reference's output class is present: fields the hot path does not
+    need are ``_Lazy`` thunks resolved on first access (so ``out.logits_per_text`` or ``out.last_hidden_state`` always
+    holds what the reference returns), and an unknown name raises instead of returning None."""
 
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, _Lazy):
+            v = v.fn()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(f"{type(self).__name__} has no field {k!r}") from None
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+class CLIPOutput(_Output):
+    """loss, logits_per_image, logits_per_text, text_embeds, image_embeds, text_model_output, vision_model_output
+    (reference CLIPOutput, CLIP_ViP.py:76-111)."""
+
+
+class BaseModelOutputWithPooling(_Output):
     def __getitem__(self, k):
         if isinstance(k, int):
             return (self["last_hidden_state"], self["pooler_output"])[k]
-        return dict.__getitem__(self, k)
+        return _Output.__getitem__(self, k)
 
 
 # ------------------------------------------------------------------------------------------ embeddings
@@ -218,7 +250,7 @@ class CLIPTextTransformer(nn.Module):
         idx = XF.H.argmax_rows(input_ids)
         ln = self.final_layer_norm
         pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias)
-        last = XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D) if (output_hidden_states or return_dict is False) else None
+        last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D))      # (:772) resolved on access
         return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled,
                                           hidden_states=None if hs is None else tuple(h.view(B, Lt, D) for h in hs))
 
@@ -467,13 +499,12 @@ class CLIPModel(CLIPPreTrainedModel):
         return self._side
 
     def _finish(self, image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict, output_hidden_states):
-        logits_per_text = logits_per_image = loss = None
-        if return_loss or return_dict is False or output_hidden_states:
-            # CLIP_ViP.py:1151-1158: tiny [B,B] fp32 product, only materialised on request (VidCLIP never asks)
-            logits_per_text = torch.matmul(text_embeds, image_embeds.t()) * self.logit_scale.exp()
-            logits_per_image = logits_per_text.T
-            if return_loss:   # clip_loss (:70-73) == NCELearnableTempLoss / 2, through the fused HIP loss kernel
-                loss = XF.NCELossFn.apply(image_embeds, text_embeds, self.logit_scale) * 0.5
+        # CLIP_ViP.py:1151-1158: tiny [B,B] fp32 product; VidCLIP never reads it, so it is resolved on access
+        logits_per_text = _Lazy(lambda: torch.matmul(text_embeds, image_embeds.t()) * self.logit_scale.exp())
+        logits_per_image = _Lazy(lambda: (torch.matmul(text_embeds, image_embeds.t()) * self.logit_scale.exp()).T)
+        loss = None          # the reference returns None as well unless return_loss (:1160-1162)
+        if return_loss:      # clip_loss (:70-73) == NCELearnableTempLoss / 2, through the fused HIP loss kernel
+            loss = XF.NCELossFn.apply(image_embeds, text_embeds, self.logit_scale) * 0.5
         return CLIPOutput(loss=loss, logits_per_image=logits_per_image, logits_per_text=logits_per_text,
                           text_embeds=text_embeds, image_embeds=image_embeds, text_model_output=text_outputs,
                           vision_model_output=vision_outputs)
