@@ -15,10 +15,11 @@ def _split(qkv, B, S, H):
     return [t.transpose(1, 2) for t in (q, k, v)]                  # [B,H,S,64]
 
 
-def _run(B, H, size, S, pad_mask, seed, scale=1.0, spike=False, q_scale=1.0):
+def _run(B, H, size, S, pad_mask, seed, scale=1.0, spike=False, q_scale=1.0, dtype=torch.bfloat16):
     from xpretrain_amd import hip_ops as Hh
     torch.manual_seed(seed)
-    qkv = (torch.randn(B * S, 3 * H * 64, device="cuda") * scale).to(torch.bfloat16)
+    tf, tb = (1.2e-2, 2e-2) if dtype == torch.bfloat16 else (2e-5, 1e-4)     # fp32 mode: exact-arithmetic kernels
+    qkv = (torch.randn(B * S, 3 * H * 64, device="cuda") * scale).to(dtype)
     if spike:   # one key late in the sequence dominates one query's row: forces m to jump at the last tile
         v = qkv.view(B, S, 3, H, 64)
         v[0, S - 1, 1, 0] = v[0, S // 2, 0, 0] * 6.0
@@ -29,16 +30,16 @@ def _run(B, H, size, S, pad_mask, seed, scale=1.0, spike=False, q_scale=1.0):
     else:
         ref = O.masked_attention_core(q, k, v, None if pad_mask is None else pad_mask.cpu().to(q.device))
     refo = ref.transpose(1, 2).reshape(B * S, H * 64)
-    tag = f"attn B{B} H{H} size{size} S{S} pad{pad_mask is not None}"
-    e1 = report(tag + " fwd", out, refo, 1.2e-2)
-    dout = torch.randn(B * S, H * 64, device="cuda").to(torch.bfloat16)
+    tag = f"attn {str(dtype)[6:]} B{B} H{H} size{size} S{S} pad{pad_mask is not None}"
+    e1 = report(tag + " fwd", out, refo, tf)
+    dout = torch.randn(B * S, H * 64, device="cuda").to(dtype)
     refo.backward(dout.double())
     dqkv = Hh.attn_bwd(qkv, out, dout, stats, B, S, H, size=size, pad_mask=pad_mask, q_scale=q_scale)
     dq, dk, dv = [t.transpose(1, 2) for t in dqkv.view(B, S, 3, H, 64).double().unbind(2)]
-    e2 = report(tag + " dq", dq, q.grad * q_scale, 2e-2)
-    e3 = report(tag + " dk", dk, k.grad, 2e-2)
-    e4 = report(tag + " dv", dv, v.grad, 2e-2)
-    assert e1 <= 1.2e-2 and e2 <= 2e-2 and e3 <= 2e-2 and e4 <= 2e-2, tag
+    e2 = report(tag + " dq", dq, q.grad * q_scale, tb)
+    e3 = report(tag + " dk", dk, k.grad, tb)
+    e4 = report(tag + " dv", dv, v.grad, tb)
+    assert e1 <= tf and e2 <= tb and e3 <= tb and e4 <= tb, tag
     assert torch.isfinite(dqkv.float()).all()
 
 
@@ -66,6 +67,26 @@ def test_causal_attention(B, S, H, mode):
             mask[1] = 0
         mask = mask.cuda()
     _run(B, H, None, S, mask, seed=S + 1)
+
+
+@pytest.mark.parametrize("size,B,H", [((4, 2, 49), 2, 2), ((4, 12, 196), 1, 2), ((1, 3, 5), 2, 1), ((4, 2, 784), 1, 1)])
+def test_proxy_attention_fp32_mode(size, B, H):
+    """the fp32 compute mode's attention kernels (csrc/attention_f32.hip) against the fp64 oracle core"""
+    M, N, L = size
+    _run(B, H, size, M + N * L, None, seed=M + N + L, dtype=torch.float32, q_scale=0.125)
+
+
+@pytest.mark.parametrize("B,S,H,mode", [(3, 12, 2, "ragged"), (2, 77, 2, "ragged"), (2, 16, 2, "allpad"), (1, 130, 1, "none")])
+def test_causal_attention_fp32_mode(B, S, H, mode):
+    torch.manual_seed(S)
+    mask = None
+    if mode != "none":
+        lens = torch.randint(1, S + 1, (B,)); lens[0] = S
+        mask = (torch.arange(S)[None] < lens[:, None]).long()
+        if mode == "allpad":
+            mask[1] = 0
+        mask = mask.cuda()
+    _run(B, H, None, S, mask, seed=S + 1, dtype=torch.float32)
 
 
 def test_attention_rejects_bad_shapes():

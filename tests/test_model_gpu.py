@@ -251,3 +251,38 @@ def test_output_fields_frozen_text_tower_and_stale_weight_guard():
     opt.step()                      # rewrites the bf16 weight copies the graph above saved
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         loss.backward()
+
+
+def test_fp32_compute_mode_against_oracle():
+    """north_star's fp32 leg ("within 1e-3 fp32"): the reference computes fp32 unless fp16 is set (run_pretrain.py:234-236).
+    BASELINE config #1 (ViT-B/32, 2 frames 224^2, 16 text tokens, batch 2) in fp32 compute mode -- fp32 MFMA GEMMs,
+    the exact-arithmetic attention kernels of csrc/attention_f32.hip, fp32 LayerNorm / embeddings / loss -- against the
+    fp32 oracle: features, loss (absolute) and every parameter gradient (relative to the tensor scale)."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    torch.manual_seed(1234)
+    cfgd = O.vit_b_config(patch=32)
+    model = VidCLIP(_Args(cfgd, 12))
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.02)
+    video, ids, mask = O.synthetic_inputs(2, 2, 224, 16)
+    cfg = O.OracleCfg.from_hf_dict(cfgd)
+    ref_loss, ref_vis, ref_txt, ref_g = _oracle_step(model, video, ids, mask, cfg, emulate=False)
+    model.cuda().train()
+    model.clipmodel.set_compute_dtype(torch.float32)
+    out = model(video.cuda(), ids.cuda(), mask.cuda())
+    loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+    loss.backward()
+    dv = (out["vis_features"].cpu() - ref_vis).abs().max().item()
+    dt = (out["text_features"].cpu() - ref_txt).abs().max().item()
+    dl = abs(loss.item() - ref_loss.item())
+    print(f"fp32 mode: loss {loss.item():.6f} oracle {ref_loss.item():.6f} |d loss| {dl:.2e} dvis {dv:.2e} dtxt {dt:.2e}")
+    assert dv <= TOL["fp32_abs"] and dt <= TOL["fp32_abs"] and dl <= TOL["fp32_abs"]
+    worst = 0.0
+    for name, p in model.named_parameters():
+        key = name[len("clipmodel."):]
+        if ref_g[key].abs().max() <= 1e-6 or name.endswith("k_proj.bias"):
+            continue
+        worst = max(worst, report(f"fp32 mode grad {name}", p.grad, ref_g[key], 5e-3))
+    print(f"fp32 mode: worst gradient error {worst:.2e}")
+    assert worst <= 5e-3

@@ -637,7 +637,7 @@ __global__ void attn_bwd_proxy_reduce_kernel(AP p) {
 
 int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L,
                  int64_t ldqkv, int64_t ldo, int32_t dtype) {
-  XP_REQUIRE(dtype == XP_BF16, "%s: only XP_BF16 is implemented for attention (got dtype %d)", name, dtype);
+  XP_REQUIRE(dtype == XP_BF16 || dtype == XP_F32, "%s: bad dtype %d", name, dtype);
   XP_REQUIRE(mode == XP_ATTN_PROXY || mode == XP_ATTN_CAUSAL, "%s: bad mode %d", name, mode);
   XP_REQUIRE(B > 0 && H > 0 && S > 0, "%s: empty problem", name);
   if (mode == XP_ATTN_PROXY) XP_REQUIRE(M >= 1 && N >= 1 && L >= 1 && S == M + N * L, "%s: S=%lld != M+N*L (%lld,%lld,%lld)",
@@ -648,6 +648,13 @@ int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S
 }
 
 }  // namespace
+
+// fp32 compute mode (attention_f32.hip): exact-arithmetic kernels, same layout / statistics / workspace contract
+int xp_attn_f32_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* stats, const int64_t* pad, int32_t mode,
+                    int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, hipStream_t st);
+int xp_attn_f32_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo, const float* stats,
+                    const int64_t* pad, void* dqkv, float q_scale, int32_t mode, int64_t B, int64_t H, int64_t S,
+                    int64_t M, int64_t N, int64_t L, float* delta_ws, hipStream_t st);
 
 static void* g_attn_trace = nullptr;
 extern "C" int xp_debug_set_attn_trace(void* device_buffer) { g_attn_trace = device_buffer; return XP_OK; }
@@ -670,6 +677,7 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   if (mode == XP_ATTN_CAUSAL) { M = 0; N = 1; L = S; }
   int rc = check_common("xp_attn_fwd", mode, B, H, S, M, N, L, ldqkv, ldo, dtype);
   if (rc) return rc;
+  if (dtype == XP_F32) return xp_attn_f32_fwd(qkv, ldqkv, out, ldo, stats, pad_mask, mode, B, H, S, M, N, L, (hipStream_t)stream);
   XP_REQUIRE(mode == XP_ATTN_CAUSAL || (workspace && workspace_bytes >= xp_attn_workspace_bytes(mode, B, H, M, N, L)),
              "xp_attn_fwd: workspace too small");
   AP p{};
@@ -698,6 +706,9 @@ extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, cons
   int rc = check_common("xp_attn_bwd", mode, B, H, S, M, N, L, ldqkv, ldo, dtype);
   if (rc) return rc;
   XP_REQUIRE(workspace && workspace_bytes >= xp_attn_workspace_bytes(mode, B, H, M, N, L), "xp_attn_bwd: workspace too small");
+  if (dtype == XP_F32)
+    return xp_attn_f32_bwd(qkv, ldqkv, out, dout, ldo, stats, pad_mask, dqkv, q_scale, mode, B, H, S, M, N, L, (float*)workspace,
+                           (hipStream_t)stream);
   AP p{};
   p.qkv = (const bf16_t*)qkv; p.ldqkv = ldqkv; p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.ldo = ldo;
   p.dqkv = (bf16_t*)dqkv; p.stats = const_cast<float*>(stats); p.pad = pad_mask; p.q_scale = q_scale;

@@ -327,8 +327,10 @@ class CLIPPreTrainedModel(nn.Module):
         self.apply(self._init_weights)
 
     def set_compute_dtype(self, dtype):
-        if dtype not in (torch.bfloat16,):
-            raise NotImplementedError("compute dtype must be torch.bfloat16 (fp32 attention kernels are not built)")
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise NotImplementedError("compute dtype must be torch.bfloat16 (the production mode) or torch.float32 (the "
+                                      "reference's default precision, pretrain/run_pretrain.py:234-236: exact-arithmetic "
+                                      "kernels for parity work, not tuned)")
         for m in self.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = dtype
