@@ -273,6 +273,51 @@ int xp_dsl_rerank(float* sim, int64_t n, int64_t m, float theta, int32_t multipl
 int xp_retrieval_ranks(const float* sim, const int64_t* labels, int64_t n, int64_t m, int32_t transpose,
                        int32_t* greater, int32_t* equal, void* stream);
 
+/* ------------------------------------------------------------------------------------ Encoder layer
+ * One CLIPEncoderLayer.forward / backward per call (modeling/CLIP_ViP.py:444-460: x + Attn(LN1(x)), then x + MLP(LN2(x));
+ * attention = CLIPAttention.forward2 :332-381 (XP_ATTN_PROXY) or .forward :266-330 (XP_ATTN_CAUSAL); MLP = CLIPMLP :392-396).
+ * Host-side sequencing of the entry points above -- launch for launch the same arithmetic as calling them one by one -- so
+ * that a training step costs ~50 native calls instead of ~800 foreign-function calls.  Activations are [rows = B*S, D]
+ * row-major in `dtype`; weights are the `dtype` copies in the reference's [out, in] layout with q/k/v concatenated row-wise
+ * (Wqkv [3D, D], bqkv [3D]); biases, LayerNorm parameters, statistics and all parameter gradients are float. */
+typedef struct XpLayerDims {
+  int64_t rows, D, Dff, B, S, heads;    /* rows == B*S, D == heads*64                                               */
+  int64_t M, N, L;                      /* XP_ATTN_PROXY: S == M + N*L; XP_ATTN_CAUSAL: pass 0, 1, S                 */
+  int32_t attn_mode, dtype;
+  float q_scale, ln_eps;                /* head_dim^-0.5 (:341), 1e-5                                                */
+} XpLayerDims;
+
+typedef struct XpLayerFwd {
+  XpLayerDims dims;
+  const void* x; const void* Wqkv; const void* Wo; const void* W1; const void* W2;
+  const float* ln1_w; const float* ln1_b; const float* bqkv; const float* bo;
+  const float* ln2_w; const float* ln2_b; const float* b1; const float* b2;
+  const int64_t* pad_mask;              /* [B,S] 1/0 or NULL (text tower)                                            */
+  /* outputs -- everything the backward needs stays in caller-owned buffers */
+  void* h1; void* qkv; void* attn_o; void* x2; void* h2; void* pre; void* act; void* x3;
+  float* mean1; float* rstd1; float* mean2; float* rstd2; float* stats;   /* stats [B,heads,S,2]                    */
+  void* workspace; size_t workspace_bytes;                                /* >= xp_encoder_layer_fwd_workspace_bytes */
+} XpLayerFwd;
+size_t xp_encoder_layer_fwd_workspace_bytes(const XpLayerDims* dims);
+int xp_encoder_layer_fwd(const XpLayerFwd* args, void* stream);
+
+typedef struct XpLayerBwd {
+  XpLayerDims dims;
+  /* saved by the forward */
+  const void* x; const void* h1; const void* qkv; const void* attn_o; const void* x2; const void* h2; const void* pre;
+  const void* act; const void* Wqkv; const void* Wo; const void* W1; const void* W2;
+  const float* ln1_w; const float* ln2_w; const float* mean1; const float* rstd1; const float* mean2; const float* rstd2;
+  const float* stats; const int64_t* pad_mask;
+  const void* dx3;                      /* gradient of the layer output                                               */
+  void* dx;                             /* gradient of the layer input                                                */
+  /* parameter gradients (float); a NULL pointer skips that gradient's kernels (frozen parameters, VidCLIP.py:96-103) */
+  float* dln1_w; float* dln1_b; float* dwqkv; float* dbqkv; float* dwo; float* dbo;
+  float* dln2_w; float* dln2_b; float* dw1; float* db1; float* dw2; float* db2;
+  void* workspace; size_t workspace_bytes;                                /* >= xp_encoder_layer_bwd_workspace_bytes */
+} XpLayerBwd;
+size_t xp_encoder_layer_bwd_workspace_bytes(const XpLayerDims* dims);
+int xp_encoder_layer_bwd(const XpLayerBwd* args, void* stream);
+
 /* -------------------------------------------------------------------------------------- Diagnostics
  * Hardware-layout probes used by tests/test_probe_gpu.py to pin the MFMA / LDS-transpose lane maps
  * this library relies on (out buffers are small device arrays; see csrc/probe.hip). */

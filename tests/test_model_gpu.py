@@ -286,3 +286,45 @@ def test_fp32_compute_mode_against_oracle():
         worst = max(worst, report(f"fp32 mode grad {name}", p.grad, ref_g[key], 5e-3))
     print(f"fp32 mode: worst gradient error {worst:.2e}")
     assert worst <= 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_native_layer_calls_equal_the_op_by_op_path(dtype):
+    """xp_encoder_layer_fwd / _bwd (csrc/layer.hip: one C-ABI call per layer pass) issue the same entry points with the same
+    arguments as the op-by-op Python path: features, loss and every gradient must be BIT-identical, incl. a frozen subset."""
+    import xpretrain_amd.functional as XF
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    torch.manual_seed(9)
+    cfgd = O.vit_b_config(16, 224)
+    cfgd["vision_config"]["num_hidden_layers"] = 2
+    cfgd["text_config"]["num_hidden_layers"] = 2
+    model = VidCLIP(_Args(cfgd, 4)).cuda().train()
+    model.clipmodel.set_compute_dtype(dtype)
+    with torch.no_grad():
+        model.clipmodel.vision_model.embeddings.temporal_embedding.normal_(0, 0.02)
+    for n, p in model.named_parameters():          # a frozen subset: the native path skips those gradients by NULL pointers
+        if "layers.1.mlp.fc1" in n or "layers.0.layer_norm2" in n or "layers.0.self_attn.k_proj.bias" in n:
+            p.requires_grad = False
+    video, ids, mask = (t.cuda() for t in O.synthetic_inputs(8 if dtype == torch.bfloat16 else 2, 4, 224, 16))
+    loss_fn = NCELearnableTempLoss()
+
+    def run(native):
+        old, XF.LAYER_CALLS = XF.LAYER_CALLS, native
+        try:
+            for p in model.parameters():
+                p.grad = None
+            out = model(video, ids, mask)
+            loss = loss_fn(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+            loss.backward()
+            return (out["vis_features"].detach().clone(), out["text_features"].detach().clone(), loss.detach().clone(),
+                    {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()})
+        finally:
+            XF.LAYER_CALLS = old
+    v1, t1, l1, g1 = run(True)
+    v0, t0, l0, g0 = run(False)
+    assert torch.equal(v1, v0) and torch.equal(t1, t0) and torch.equal(l1, l0)
+    for n in g0:
+        assert (g0[n] is None) == (g1[n] is None), n
+        if g0[n] is not None:
+            assert torch.equal(g0[n], g1[n]), n

@@ -50,6 +50,28 @@ class XpReduceSeg(C.Structure):
 XP_REDUCE_MAX_SEGS = 16
 
 
+class XpLayerDims(C.Structure):
+    _fields_ = [("rows", i64), ("D", i64), ("Dff", i64), ("B", i64), ("S", i64), ("heads", i64),
+                ("M", i64), ("N", i64), ("L", i64), ("attn_mode", i32), ("dtype", i32), ("q_scale", f32), ("ln_eps", f32)]
+
+
+class XpLayerFwd(C.Structure):
+    _fields_ = ([("dims", XpLayerDims)]
+                + [(n, vp) for n in ("x", "Wqkv", "Wo", "W1", "W2", "ln1_w", "ln1_b", "bqkv", "bo", "ln2_w", "ln2_b", "b1", "b2",
+                                     "pad_mask", "h1", "qkv", "attn_o", "x2", "h2", "pre", "act", "x3", "mean1", "rstd1",
+                                     "mean2", "rstd2", "stats", "workspace")]
+                + [("workspace_bytes", sz)])
+
+
+class XpLayerBwd(C.Structure):
+    _fields_ = ([("dims", XpLayerDims)]
+                + [(n, vp) for n in ("x", "h1", "qkv", "attn_o", "x2", "h2", "pre", "act", "Wqkv", "Wo", "W1", "W2", "ln1_w",
+                                     "ln2_w", "mean1", "rstd1", "mean2", "rstd2", "stats", "pad_mask", "dx3", "dx",
+                                     "dln1_w", "dln1_b", "dwqkv", "dbqkv", "dwo", "dbo", "dln2_w", "dln2_b", "dw1", "db1",
+                                     "dw2", "db2", "workspace")]
+                + [("workspace_bytes", sz)])
+
+
 class XpAdamTensor(C.Structure):
     _fields_ = [("p", vp), ("m", vp), ("v", vp), ("shadow", vp), ("numel", i64), ("shadow_dtype", i32), ("reserved", i32)]
 
@@ -106,6 +128,10 @@ SIGNATURES = {
     "xp_retrieval_ranks": (i32, [vp, vp, i64, i64, i32, vp, vp, vp]),
     "xp_vsc_fc_loss_workspace_bytes": (sz, [i64, i64]),
     "xp_vsc_fc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, sz, vp]),
+    "xp_encoder_layer_fwd_workspace_bytes": (sz, [C.POINTER(XpLayerDims)]),
+    "xp_encoder_layer_fwd": (i32, [C.POINTER(XpLayerFwd), vp]),
+    "xp_encoder_layer_bwd_workspace_bytes": (sz, [C.POINTER(XpLayerDims)]),
+    "xp_encoder_layer_bwd": (i32, [C.POINTER(XpLayerBwd), vp]),
     "xp_debug_set_gemm_trace": (i32, [vp]),
     "xp_debug_set_attn_trace": (i32, [vp]),
     "xp_debug_gemm_occupancy": (i32, [i32]),

@@ -1,0 +1,221 @@
+// One CLIPEncoderLayer pass per C-ABI call (modeling/CLIP_ViP.py:444-460 with CLIPAttention.forward2 :332-381 or
+// .forward :266-330 and CLIPMLP :392-396): the 8 forward / ~21 backward kernel launches of a layer are issued from native
+// code.  Pure host-side sequencing over the public entry points of this library (xp_layernorm_*, xp_gemm, xp_attn_*,
+// xp_colsum_partials, xp_splitk_reduce, xp_reduce_rows_batch) -- no kernel of its own -- so the arithmetic is identical,
+// launch for launch, to driving those entry points one by one (the Python op-by-op path, functional.EncoderLayerFn with
+// XPRETRAIN_LAYER_CALLS=0; tests compare the two bit for bit).  Why: ~810 launches per training step cost 13.6 ms of
+// Python / ctypes time against 16.7 ms of GPU time (BENCH_r01); from C++ a launch costs 3-4 us.
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Carver {            // bump allocator over the caller's workspace
+  char* base; size_t off, cap;
+  void* take(size_t n) { void* p = base ? base + off : nullptr; off += align256(n); return p; }
+};
+
+XpGemmDesc gemm_desc(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int dtype) {
+  XpGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K;
+  d.lda = K; d.ldb = K; d.ldc = N; d.ldr = N; d.ldaux = N;
+  d.in_dtype = dtype; d.out_dtype = dtype; d.split_k = 1; d.scale = 1.0f;
+  return d;
+}
+
+// dW[n_out, n_in] = dY[rows, n_out]^T . X[rows, n_in], fp32: both operands k-strided, split-K chosen by the library
+int wgrad(const void* dy, const void* x, float* dw, int64_t rows, int64_t n_out, int64_t n_in, int dtype, float* slabs,
+          size_t slab_bytes, void* st) {
+  XpGemmDesc d = gemm_desc(dy, x, dw, n_out, n_in, rows, dtype);
+  d.a_kstrided = d.b_kstrided = 1; d.lda = n_out; d.ldb = n_in; d.out_dtype = XP_F32;
+  const int split = xp_gemm_auto_split(&d);
+  if (split <= 1) return xp_gemm(&d, st);
+  XP_REQUIRE(slab_bytes >= (size_t)split * n_out * n_in * sizeof(float), "xp_encoder_layer_bwd: split-K slab space too small");
+  d.C = slabs; d.split_k = split;
+  int rc = xp_gemm(&d, st);
+  if (rc) return rc;
+  return xp_splitk_reduce(slabs, dw, n_out * n_in, split, 0, st);
+}
+
+size_t wgrad_slab_bytes(int64_t rows, int64_t n_out, int64_t n_in, int dtype) {
+  XpGemmDesc d = gemm_desc(nullptr, nullptr, nullptr, n_out, n_in, rows, dtype);
+  d.a_kstrided = d.b_kstrided = 1; d.lda = n_out; d.ldb = n_in; d.out_dtype = XP_F32;
+  const int split = xp_gemm_auto_split(&d);
+  return split <= 1 ? 0 : (size_t)split * n_out * n_in * sizeof(float);
+}
+
+struct Defer {             // the layer's deferred second-level reductions (bias / LayerNorm-parameter gradients)
+  XpReduceSeg segs[XP_REDUCE_MAX_SEGS]; int n = 0;
+  void add(const float* in, float* out, int64_t stride, int nrows, int width) {
+    if (!out) return;
+    XpReduceSeg& s = segs[n++];
+    s.in = in; s.out = out; s.stride = stride; s.nrows = nrows; s.width = width; s.accumulate = 0; s.reserved = 0;
+  }
+};
+
+int check_dims(const char* name, const XpLayerDims& d) {
+  XP_REQUIRE(d.rows > 0 && d.D > 0 && d.Dff > 0 && d.B > 0 && d.S > 0 && d.heads > 0, "%s: empty dimension", name);
+  XP_REQUIRE(d.rows == d.B * d.S && d.D == d.heads * 64, "%s: rows != B*S or D != heads*64", name);
+  XP_REQUIRE(d.dtype == XP_BF16 || d.dtype == XP_F32, "%s: bad dtype %d", name, d.dtype);
+  return XP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t xp_encoder_layer_fwd_workspace_bytes(const XpLayerDims* d) {
+  if (!d) return 0;
+  return xp_attn_workspace_bytes(d->attn_mode, d->B, d->heads, d->M, d->N, d->L) + 256;
+}
+
+extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
+  XP_REQUIRE(a, "xp_encoder_layer_fwd: null argument");
+  const XpLayerDims& d = a->dims;
+  int rc = check_dims("xp_encoder_layer_fwd", d);
+  if (rc) return rc;
+  XP_REQUIRE(a->x && a->Wqkv && a->Wo && a->W1 && a->W2 && a->ln1_w && a->ln1_b && a->bqkv && a->bo && a->ln2_w && a->ln2_b &&
+             a->b1 && a->b2 && a->h1 && a->qkv && a->attn_o && a->x2 && a->h2 && a->pre && a->act && a->x3 && a->mean1 &&
+             a->rstd1 && a->mean2 && a->rstd2 && a->stats, "xp_encoder_layer_fwd: null pointer");
+  const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
+  const int dt = d.dtype;
+  // h1 = LN1(x)
+  if ((rc = xp_layernorm_fwd(a->x, D, a->ln1_w, a->ln1_b, a->h1, D, a->mean1, a->rstd1, rows, D, d.ln_eps, dt, st))) return rc;
+  // qkv = (h1 Wqkv^T + b), q columns scaled by dh^-0.5 (:341)
+  XpGemmDesc g = gemm_desc(a->h1, a->Wqkv, a->qkv, rows, 3 * D, D, dt);
+  g.epilogue = XP_EPI_BIAS_QSCALE; g.bias = a->bqkv; g.scale = d.q_scale; g.scale_cols = D;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  if ((rc = xp_attn_fwd(a->qkv, 3 * D, a->attn_o, D, a->stats, a->pad_mask, d.attn_mode, d.B, d.heads, d.S, d.M, d.N, d.L, dt,
+                        a->workspace, a->workspace_bytes, st))) return rc;
+  // x2 = x + attn_o Wo^T + bo
+  g = gemm_desc(a->attn_o, a->Wo, a->x2, rows, D, D, dt);
+  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->bo; g.resid = a->x;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  if ((rc = xp_layernorm_fwd(a->x2, D, a->ln2_w, a->ln2_b, a->h2, D, a->mean2, a->rstd2, rows, D, d.ln_eps, dt, st))) return rc;
+  // pre = h2 W1^T + b1 ; act = quick_gelu(pre)
+  g = gemm_desc(a->h2, a->W1, a->act, rows, Dff, D, dt);
+  g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  // x3 = x2 + act W2^T + b2
+  g = gemm_desc(a->act, a->W2, a->x3, rows, D, Dff, dt);
+  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->b2; g.resid = a->x2;
+  return xp_gemm(&g, st);
+}
+
+// workspace layout of the backward: [dpre | dh2 | dx2 | dattn | dqkv | dh1] activations-gradient temporaries, split-K slabs,
+// six deferred partial-row slots, the batched-reduce scratch, the attention workspace
+namespace {
+struct BwdPlan {
+  size_t esz, dpre, dh, dqkv, slabs, cs_pre, cs_dx3, ln2, cs_qkv, ln1, red, attn, total;
+  int64_t cs_pre_rows, cs_dx3_rows, cs_qkv_rows, ln_rows;
+};
+BwdPlan plan_bwd(const XpLayerDims& d) {
+  BwdPlan p;
+  memset(&p, 0, sizeof(p));
+  const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
+  p.esz = d.dtype == XP_BF16 ? 2 : 4;
+  p.dpre = align256(rows * Dff * p.esz); p.dh = align256(rows * D * p.esz); p.dqkv = align256(rows * 3 * D * p.esz);
+  size_t s = wgrad_slab_bytes(rows, D, Dff, d.dtype);
+  size_t t = wgrad_slab_bytes(rows, Dff, D, d.dtype); if (t > s) s = t;
+  t = wgrad_slab_bytes(rows, D, D, d.dtype); if (t > s) s = t;
+  t = wgrad_slab_bytes(rows, 3 * D, D, d.dtype); if (t > s) s = t;
+  p.slabs = align256(s);
+  // fc1's bias gradient: fused into the dX GEMM epilogue where the library offers it, else a column-sum pass over dpre
+  XpGemmDesc g = gemm_desc(nullptr, nullptr, nullptr, rows, Dff, D, d.dtype);
+  g.b_kstrided = 1; g.ldb = Dff; g.epilogue = XP_EPI_GELU_BWD; g.ldr = Dff;
+  g.resid = &g;                          // (only tested for non-NULL by the planning queries)
+  p.cs_pre_rows = xp_gemm_colsum_rows(&g);
+  const int64_t pre_rows = p.cs_pre_rows > 0 ? p.cs_pre_rows : xp_colsum_partial_rows(rows, Dff);
+  p.cs_pre = align256(pre_rows * Dff * sizeof(float));
+  p.cs_dx3_rows = xp_colsum_partial_rows(rows, D); p.cs_dx3 = align256(p.cs_dx3_rows * D * sizeof(float));
+  p.cs_qkv_rows = xp_colsum_partial_rows(rows, 3 * D); p.cs_qkv = align256(p.cs_qkv_rows * 3 * D * sizeof(float));
+  p.ln_rows = xp_layernorm_bwd_partial_rows(rows);
+  p.ln2 = p.ln1 = align256(xp_layernorm_bwd_workspace_bytes(rows, D));
+  p.red = align256((size_t)XP_REDUCE_MAX_SEGS * 32 * (size_t)(3 * D > Dff ? 3 * D : Dff) * sizeof(float) + 16);
+  p.attn = align256(xp_attn_workspace_bytes(d.attn_mode, d.B, d.heads, d.M, d.N, d.L));
+  p.total = p.dpre + 4 * p.dh + p.dqkv + p.slabs + p.cs_pre + p.cs_dx3 + p.ln2 + p.cs_qkv + p.ln1 + p.red + p.attn + 256;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t xp_encoder_layer_bwd_workspace_bytes(const XpLayerDims* d) {
+  if (!d || d->rows <= 0) return 0;
+  return plan_bwd(*d).total;
+}
+
+extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
+  XP_REQUIRE(a, "xp_encoder_layer_bwd: null argument");
+  const XpLayerDims& d = a->dims;
+  int rc = check_dims("xp_encoder_layer_bwd", d);
+  if (rc) return rc;
+  XP_REQUIRE(a->x && a->h1 && a->qkv && a->attn_o && a->x2 && a->h2 && a->pre && a->act && a->Wqkv && a->Wo && a->W1 && a->W2 &&
+             a->ln1_w && a->ln2_w && a->mean1 && a->rstd1 && a->mean2 && a->rstd2 && a->stats && a->dx3 && a->dx,
+             "xp_encoder_layer_bwd: null pointer");
+  const BwdPlan p = plan_bwd(d);
+  XP_REQUIRE(a->workspace && a->workspace_bytes >= p.total, "xp_encoder_layer_bwd: workspace too small (%zu < %zu)",
+             a->workspace_bytes, p.total);
+  Carver ws{(char*)a->workspace, 0, a->workspace_bytes};
+  void* dpre = ws.take(p.dpre); void* dh2 = ws.take(p.dh); void* dx2 = ws.take(p.dh); void* dattn = ws.take(p.dh);
+  void* dqkv = ws.take(p.dqkv); void* dh1 = ws.take(p.dh);
+  float* slabs = (float*)ws.take(p.slabs);
+  float* cs_pre = (float*)ws.take(p.cs_pre); float* cs_dx3 = (float*)ws.take(p.cs_dx3);
+  float* ln2_part = (float*)ws.take(p.ln2); float* cs_qkv = (float*)ws.take(p.cs_qkv); float* ln1_part = (float*)ws.take(p.ln1);
+  void* red_ws = ws.take(p.red); void* attn_ws = ws.take(p.attn);
+  const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
+  const int dt = d.dtype;
+  Defer df;
+
+  // ---- MLP: x3 = x2 + fc2(quick_gelu(fc1(LN2(x2))))
+  XpGemmDesc g = gemm_desc(a->dx3, a->W2, dpre, rows, Dff, D, dt);            // dpre = (dx3 . W2) * quick_gelu'(pre)
+  g.b_kstrided = 1; g.ldb = Dff; g.epilogue = XP_EPI_GELU_BWD; g.resid = a->pre; g.ldr = Dff;
+  if (a->db1 && p.cs_pre_rows > 0) g.colsum_partials = cs_pre;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  if (a->db1) {
+    if (p.cs_pre_rows > 0) df.add(cs_pre, a->db1, Dff, (int)p.cs_pre_rows, (int)Dff);
+    else {
+      const int64_t r = xp_colsum_partial_rows(rows, Dff);
+      if ((rc = xp_colsum_partials(dpre, rows, Dff, Dff, dt, cs_pre, p.cs_pre, st))) return rc;
+      df.add(cs_pre, a->db1, Dff, (int)r, (int)Dff);
+    }
+  }
+  if (a->dw2 && (rc = wgrad(a->dx3, a->act, a->dw2, rows, D, Dff, dt, slabs, p.slabs, st))) return rc;
+  if (a->db2) {
+    if ((rc = xp_colsum_partials(a->dx3, rows, D, D, dt, cs_dx3, p.cs_dx3, st))) return rc;
+    df.add(cs_dx3, a->db2, D, (int)p.cs_dx3_rows, (int)D);
+  }
+  g = gemm_desc(dpre, a->W1, dh2, rows, D, Dff, dt);                          // dh2 = dpre . W1
+  g.b_kstrided = 1; g.ldb = D;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, st))) return rc;
+  // dx2 = dx3 + LN2'(dh2); partial rows [dgamma | dbeta | colsum(dx2)] -- the last one is out_proj's bias gradient
+  if ((rc = xp_layernorm_bwd_partials(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 1, rows, D, dt,
+                                      ln2_part, p.ln2, st))) return rc;
+  df.add(ln2_part, a->dln2_w, 3 * D, (int)p.ln_rows, (int)D);
+  df.add(ln2_part + D, a->dln2_b, 3 * D, (int)p.ln_rows, (int)D);
+  df.add(ln2_part + 2 * D, a->dbo, 3 * D, (int)p.ln_rows, (int)D);
+  // ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
+  g = gemm_desc(dx2, a->Wo, dattn, rows, D, D, dt);                           // dattn = dx2 . Wo
+  g.b_kstrided = 1; g.ldb = D;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  if (a->dwo && (rc = wgrad(dx2, a->attn_o, a->dwo, rows, D, D, dt, slabs, p.slabs, st))) return rc;
+  if ((rc = xp_attn_bwd(a->qkv, 3 * D, a->attn_o, dattn, D, a->stats, a->pad_mask, dqkv, d.q_scale, d.attn_mode, d.B, d.heads,
+                        d.S, d.M, d.N, d.L, dt, attn_ws, p.attn, st))) return rc;
+  g = gemm_desc(dqkv, a->Wqkv, dh1, rows, D, 3 * D, dt);                      // dh1 = dqkv . Wqkv
+  g.b_kstrided = 1; g.ldb = D;
+  if ((rc = xp_gemm(&g, st))) return rc;
+  if (a->dwqkv && (rc = wgrad(dqkv, a->h1, a->dwqkv, rows, 3 * D, D, dt, slabs, p.slabs, st))) return rc;
+  if (a->dbqkv) {
+    if ((rc = xp_colsum_partials(dqkv, rows, 3 * D, 3 * D, dt, cs_qkv, p.cs_qkv, st))) return rc;
+    df.add(cs_qkv, a->dbqkv, 3 * D, (int)p.cs_qkv_rows, (int)(3 * D));
+  }
+  if ((rc = xp_layernorm_bwd_partials(dh1, D, a->x, D, a->ln1_w, a->mean1, a->rstd1, dx2, D, a->dx, D, 0, rows, D, dt,
+                                      ln1_part, p.ln1, st))) return rc;
+  df.add(ln1_part, a->dln1_w, 2 * D, (int)p.ln_rows, (int)D);
+  df.add(ln1_part + D, a->dln1_b, 2 * D, (int)p.ln_rows, (int)D);
+  if (df.n) {
+    XP_REQUIRE(xp_reduce_rows_batch_workspace_bytes(df.segs, df.n) <= p.red, "xp_encoder_layer_bwd: reduce scratch too small");
+    if ((rc = xp_reduce_rows_batch(df.segs, df.n, red_ws, p.red, st))) return rc;
+  }
+  return XP_OK;
+}

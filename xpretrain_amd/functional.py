@@ -12,6 +12,8 @@ Reference call sites are cited per class (paths relative to /root/reference/CLIP
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -164,6 +166,116 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, 
     return dw
 
 
+# ------------------------------------------------------------------------------------------ encoder layer, native sequencing
+# XPRETRAIN_LAYER_CALLS=1 (default): one C-ABI call per layer pass (xp_encoder_layer_fwd / _bwd, csrc/layer.hip) -- the same
+# entry points in the same order with the same arguments as the op-by-op path below, issued from native code; =0 keeps the
+# op-by-op path (tools/determinism_hunt.py fingerprints every call of it; tests compare the two paths bit for bit).
+LAYER_CALLS = os.environ.get("XPRETRAIN_LAYER_CALLS", "1") != "0"
+_DT_CODE = {torch.bfloat16: L.XP_BF16, torch.float32: L.XP_F32}
+_ES = {torch.bfloat16: 2, torch.float32: 4}
+_PLANS = {}
+
+
+def _a256(n: int) -> int:
+    return (n + 255) & ~255
+
+
+class _LayerPlan:
+    """Sizes / offsets of one (shape, dtype) of encoder layer: the saved-activation arena of the forward, the flat
+    parameter-gradient buffer of the backward, the workspace sizes."""
+
+    def __init__(self, rows, D, Dff, B, S, heads, size, dtype):
+        d = L.XpLayerDims()
+        d.rows, d.D, d.Dff, d.B, d.S, d.heads = rows, D, Dff, B, S, heads
+        d.M, d.N, d.L = size if size is not None else (0, 1, S)
+        d.attn_mode = L.ATTN_PROXY if size is not None else L.ATTN_CAUSAL
+        d.dtype, d.q_scale, d.ln_eps = _DT_CODE[dtype], (D // heads) ** -0.5, 1e-5
+        self.dims = d
+        es = _ES[dtype]
+        # arena: bf16/fp32 activations then fp32 statistics, 256-byte aligned pieces
+        self.off, o = {}, 0
+        for name, n in (("h1", rows * D * es), ("qkv", rows * 3 * D * es), ("attn_o", rows * D * es), ("x2", rows * D * es),
+                        ("h2", rows * D * es), ("pre", rows * Dff * es), ("act", rows * Dff * es), ("mean1", rows * 4),
+                        ("rstd1", rows * 4), ("mean2", rows * 4), ("rstd2", rows * 4), ("stats", B * heads * S * 2 * 4)):
+            self.off[name] = o
+            o += _a256(n)
+        self.arena_bytes = o
+        lib = L.lib()
+        self.fwd_ws = int(lib.xp_encoder_layer_fwd_workspace_bytes(C.byref(d)))
+        self.bwd_ws = int(lib.xp_encoder_layer_bwd_workspace_bytes(C.byref(d)))
+        # flat fp32 parameter gradients, in the order of EncoderLayerFn.forward's parameter arguments
+        self.gsizes = [D, D, 3 * D * D, 3 * D, D * D, D, D, D, Dff * D, Dff, D * Dff, D]
+        self.gnames = ["dln1_w", "dln1_b", "dwqkv", "dbqkv", "dwo", "dbo", "dln2_w", "dln2_b", "dw1", "db1", "dw2", "db2"]
+        self.gtotal = sum(self.gsizes)
+
+
+def _layer_plan(rows, D, Dff, B, S, heads, size, dtype) -> _LayerPlan:
+    key = (rows, D, Dff, B, S, heads, size, dtype)
+    p = _PLANS.get(key)
+    if p is None:
+        p = _PLANS[key] = _LayerPlan(*key)
+    return p
+
+
+def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask):
+    dev = x.device
+    arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
+    x3 = torch.empty_like(x)
+    ws = H.workspace(plan.fwd_ws, dev, "layer_fwd")
+    a = L.XpLayerFwd()
+    a.dims = plan.dims
+    a.x, a.Wqkv, a.Wo, a.W1, a.W2 = x.data_ptr(), Wqkv.data_ptr(), Wo.data_ptr(), W1.data_ptr(), W2.data_ptr()
+    a.ln1_w, a.ln1_b, a.bqkv, a.bo = ln1_w.data_ptr(), ln1_b.data_ptr(), bqkv.data_ptr(), bo.data_ptr()
+    a.ln2_w, a.ln2_b, a.b1, a.b2 = ln2_w.data_ptr(), ln2_b.data_ptr(), b1.data_ptr(), b2.data_ptr()
+    a.pad_mask = 0 if pad_mask is None else pad_mask.data_ptr()
+    base, off = arena.data_ptr(), plan.off
+    a.h1, a.qkv, a.attn_o, a.x2, a.h2 = base + off["h1"], base + off["qkv"], base + off["attn_o"], base + off["x2"], base + off["h2"]
+    a.pre, a.act, a.x3 = base + off["pre"], base + off["act"], x3.data_ptr()
+    a.mean1, a.rstd1, a.mean2, a.rstd2 = base + off["mean1"], base + off["rstd1"], base + off["mean2"], base + off["rstd2"]
+    a.stats = base + off["stats"]
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().xp_encoder_layer_fwd(C.byref(a), H._stream()), "xp_encoder_layer_fwd")
+    return x3, arena
+
+
+def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, plan):
+    dev = x.device
+    need = ctx.needs_input_grad
+    dx = torch.empty_like(x)
+    flat = torch.empty(plan.gtotal, dtype=torch.float32, device=dev)
+    parts = flat.split_with_sizes(plan.gsizes)
+    ws = H.workspace(plan.bwd_ws, dev, "layer_bwd")
+    a = L.XpLayerBwd()
+    a.dims = plan.dims
+    base, off = arena.data_ptr(), plan.off
+    a.x, a.h1, a.qkv, a.attn_o, a.x2 = x.data_ptr(), base + off["h1"], base + off["qkv"], base + off["attn_o"], base + off["x2"]
+    a.h2, a.pre, a.act = base + off["h2"], base + off["pre"], base + off["act"]
+    a.Wqkv, a.Wo, a.W1, a.W2 = Wqkv.data_ptr(), Wo.data_ptr(), W1.data_ptr(), W2.data_ptr()
+    a.ln1_w, a.ln2_w = ln1_w.data_ptr(), ln2_w.data_ptr()
+    a.mean1, a.rstd1, a.mean2, a.rstd2 = base + off["mean1"], base + off["rstd1"], base + off["mean2"], base + off["rstd2"]
+    a.stats = base + off["stats"]
+    a.pad_mask = 0 if pad_mask is None else pad_mask.data_ptr()
+    a.dx3, a.dx = dx3.data_ptr(), dx.data_ptr()
+    # forward argument positions: 1,2 ln1 | 3..8 wq,bq,wk,bk,wv,bv | 9,10 wo,bo | 11,12 ln2 | 13,14 w1,b1 | 15,16 w2,b2
+    want = dict(dln1_w=need[1], dln1_b=need[2], dwqkv=need[3] or need[5] or need[7], dbqkv=need[4] or need[6] or need[8],
+                dwo=need[9], dbo=need[10], dln2_w=need[11], dln2_b=need[12], dw1=need[13], db1=need[14], dw2=need[15], db2=need[16])
+    g = {}
+    for name, t in zip(plan.gnames, parts):
+        if want[name]:
+            g[name] = t
+            setattr(a, name, t.data_ptr())
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().xp_encoder_layer_bwd(C.byref(a), H._stream()), "xp_encoder_layer_bwd")
+    D, Dff = plan.dims.D, plan.dims.Dff
+    gw = lambda n, shape: g[n].view(shape) if n in g else None
+    dwqkv, dbqkv = gw("dwqkv", (3 * D, D)), g.get("dbqkv")
+    pick = lambda t, i, ok: t[i * D:(i + 1) * D] if (t is not None and ok) else None
+    return (dx, g.get("dln1_w"), g.get("dln1_b"),
+            pick(dwqkv, 0, need[3]), pick(dbqkv, 0, need[4]), pick(dwqkv, 1, need[5]), pick(dbqkv, 1, need[6]),
+            pick(dwqkv, 2, need[7]), pick(dbqkv, 2, need[8]), gw("dwo", (D, D)), g.get("dbo"), g.get("dln2_w"), g.get("dln2_b"),
+            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None)
+
+
 # ------------------------------------------------------------------------------------------ encoder layer
 class EncoderLayerFn(torch.autograd.Function):
     """CLIPEncoderLayer.forward (modeling/CLIP_ViP.py:444-460) with CLIPAttention.forward2 (:332-381, video
@@ -183,6 +295,13 @@ class EncoderLayerFn(torch.autograd.Function):
         Wqkv = WEIGHTS.fused((wq, wk, wv), dt)
         bqkv = WEIGHTS.fused((bq, bk, bv), torch.float32)
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
+        if LAYER_CALLS and x.is_contiguous():
+            plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
+            x3, arena = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask)
+            ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask)
+            ctx.plan = plan
+            return x3
+        ctx.plan = None
 
         h1, mean1, rstd1 = H.layernorm_fwd(x, ln1_w, ln1_b, rows, D)
         qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D)
@@ -200,6 +319,9 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx3):
+        if ctx.plan is not None:
+            x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask = ctx.saved_tensors
+            return _layer_bwd_native(ctx, dx3.contiguous(), x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, ctx.plan)
         (x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
          Wqkv, Wo, W1, W2, pad_mask) = ctx.saved_tensors
         B, S, heads, size, q_scale, D, Dff = ctx.meta
