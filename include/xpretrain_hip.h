@@ -47,7 +47,8 @@ enum {
   XP_EPI_NONE = 0,       /* C = acc                                                              */
   XP_EPI_BIAS = 1,       /* C = acc + bias[n]                                                    */
   XP_EPI_BIAS_QSCALE = 2,/* C = (acc + bias[n]) * (n < scale_cols ? scale : 1)   q*dh^-0.5 (:341)  */
-  XP_EPI_BIAS_GELU = 3,  /* aux = acc + bias[n];  C = aux * sigmoid(1.702 aux)   quick_gelu (:394) */
+  XP_EPI_BIAS_GELU = 3,  /* aux = acc + bias[n];  C = aux * sigmoid(1.702 aux)   quick_gelu (:394); aux == NULL: the
+                          * pre-activation is not stored (forward-only passes: retrieval / inference)        */
   XP_EPI_BIAS_RESID = 4, /* C = acc + bias[n] + resid[m,n]                       (:455,:460)       */
   XP_EPI_GELU_BWD = 5,   /* C = acc * d/dx quick_gelu(resid[m,n])                                 */
   XP_EPI_PATCH = 6,      /* C = acc + tab1[t,n] + tab2[l,n], t=(m%c_grp)/tab_L, l=m%tab_L (:182-185) */
@@ -293,7 +294,8 @@ typedef struct XpLayerFwd {
   const float* ln1_w; const float* ln1_b; const float* bqkv; const float* bo;
   const float* ln2_w; const float* ln2_b; const float* b1; const float* b2;
   const int64_t* pad_mask;              /* [B,S] 1/0 or NULL (text tower)                                            */
-  /* outputs -- everything the backward needs stays in caller-owned buffers */
+  /* outputs -- everything the backward needs stays in caller-owned buffers; pre == NULL: forward-only pass, the MLP
+   * pre-activation (needed by the backward alone) is not written */
   void* h1; void* qkv; void* attn_o; void* x2; void* h2; void* pre; void* act; void* x3;
   float* mean1; float* rstd1; float* mean2; float* rstd2; float* stats;   /* stats [B,heads,S,2]                    */
   void* workspace; size_t workspace_bytes;                                /* >= xp_encoder_layer_fwd_workspace_bytes */

@@ -227,6 +227,10 @@ def test_output_fields_frozen_text_tower_and_stale_weight_guard():
     assert out.loss is None
     with pytest.raises(AttributeError):
         out.no_such_field
+    # forward-only passes (torch.no_grad) skip the MLP pre-activation output: same features, bit for bit
+    with torch.no_grad():
+        o_ng = model.clipmodel(input_ids=ids, pixel_values=video, attention_mask=mask)
+    assert torch.equal(o_ng.image_embeds, out.image_embeds) and torch.equal(o_ng.text_embeds, out.text_embeds)
     # (2)
     loss_fn = NCELearnableTempLoss()
 

@@ -552,7 +552,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   if (ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID)
     XP_REQUIRE(d->bias, "xp_gemm: epilogue %d needs bias", ep);
   if (ep == XP_EPI_BIAS_RESID || ep == XP_EPI_GELU_BWD) XP_REQUIRE(d->resid && d->ldr % 4 == 0, "xp_gemm: epilogue %d needs resid", ep);
-  if (ep == XP_EPI_BIAS_GELU) XP_REQUIRE(d->aux && d->ldaux % 4 == 0, "xp_gemm: epilogue BIAS_GELU needs aux");
+  if (ep == XP_EPI_BIAS_GELU) XP_REQUIRE(!d->aux || d->ldaux % 4 == 0, "xp_gemm: epilogue BIAS_GELU: bad ldaux");
   if (ep == XP_EPI_PATCH) XP_REQUIRE(d->tab1 && d->tab2 && d->tab_L > 0, "xp_gemm: epilogue PATCH needs tab1/tab2/tab_L");
   const int split = d->split_k > 1 ? d->split_k : 1;
   if (split > 1) XP_REQUIRE(ep == XP_EPI_NONE && d->out_dtype == XP_F32 && d->c_grp == 0 && d->ldc == d->N,

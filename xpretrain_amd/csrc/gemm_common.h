@@ -50,8 +50,9 @@ __device__ __forceinline__ void epi_row(const KParams& p, const EpiLane& el, f32
   v = (v + el.bias) * el.colscale;
   const int64_t crow = p.cmap(m);
   if (ep == XP_EPI_BIAS_GELU) {
-    if (p.out_f32) store4(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
-    else           store4(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
+    if (!p.aux) {}                                   // forward-only: the pre-activation is not kept
+    else if (p.out_f32) store4(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
+    else                store4(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
   } else if (ep == XP_EPI_BIAS_RESID) {
@@ -83,8 +84,9 @@ __device__ __forceinline__ void epi_row8(const KParams& p, const EpiLane8& el, f
   v.lo = (v.lo + el.bias.lo) * el.cs_lo; v.hi = (v.hi + el.bias.hi) * el.cs_hi;
   const int64_t crow = p.cmap(m);
   if (ep == XP_EPI_BIAS_GELU) {
-    if (p.out_f32) store8(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
-    else           store8(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
+    if (!p.aux) {}                                   // forward-only: the pre-activation is not kept
+    else if (p.out_f32) store8(reinterpret_cast<float*>(p.aux) + crow * p.ldaux + n, v);
+    else                store8(reinterpret_cast<T*>(p.aux) + crow * p.ldaux + n, v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
   } else if (ep == XP_EPI_BIAS_RESID) {
@@ -157,9 +159,10 @@ struct FastEpi {
   f32x8 bias; float cs_lo, cs_hi;
   unsigned ld_c, ld_x;      // row pitch in bytes
   unsigned col_c, col_x;    // byte offset of column n
-  bool ok;
+  bool ok, keep_aux;
   __device__ __forceinline__ FastEpi(const KParams& p, void* Cbase, int64_t n) {
     ok = n < p.N;
+    keep_aux = p.aux != nullptr;             // BIAS_GELU without aux: forward-only, the pre-activation is not stored
     const int64_t nn = ok ? n : 0;
     rc = __builtin_amdgcn_make_buffer_rsrc(Cbase, 0, (unsigned)(p.M * p.ldc * OSZ), 0x00020000);
     ld_c = (unsigned)(p.ldc * OSZ); col_c = (unsigned)(nn * OSZ);
@@ -181,7 +184,7 @@ struct FastEpi {
     if constexpr (Tr::bias) { v.lo += bias.lo; v.hi += bias.hi; }
     if constexpr (Tr::scale) { v.lo *= cs_lo; v.hi *= cs_hi; }
     if constexpr (EPI == XP_EPI_BIAS_GELU) {
-      bstore8<T, F32>(rx, off_x(m), v);
+      if (keep_aux) bstore8<T, F32>(rx, off_x(m), v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
     } else if constexpr (EPI == XP_EPI_BIAS_RESID) {

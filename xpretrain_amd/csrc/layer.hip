@@ -76,7 +76,7 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
   int rc = check_dims("xp_encoder_layer_fwd", d);
   if (rc) return rc;
   XP_REQUIRE(a->x && a->Wqkv && a->Wo && a->W1 && a->W2 && a->ln1_w && a->ln1_b && a->bqkv && a->bo && a->ln2_w && a->ln2_b &&
-             a->b1 && a->b2 && a->h1 && a->qkv && a->attn_o && a->x2 && a->h2 && a->pre && a->act && a->x3 && a->mean1 &&
+             a->b1 && a->b2 && a->h1 && a->qkv && a->attn_o && a->x2 && a->h2 && a->act && a->x3 && a->mean1 &&
              a->rstd1 && a->mean2 && a->rstd2 && a->stats, "xp_encoder_layer_fwd: null pointer");
   const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
   const int dt = d.dtype;

@@ -217,7 +217,7 @@ def _layer_plan(rows, D, Dff, B, S, heads, size, dtype) -> _LayerPlan:
     return p
 
 
-def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask):
+def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True):
     dev = x.device
     arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
     x3 = torch.empty_like(x)
@@ -230,7 +230,7 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
     a.pad_mask = 0 if pad_mask is None else pad_mask.data_ptr()
     base, off = arena.data_ptr(), plan.off
     a.h1, a.qkv, a.attn_o, a.x2, a.h2 = base + off["h1"], base + off["qkv"], base + off["attn_o"], base + off["x2"], base + off["h2"]
-    a.pre, a.act, a.x3 = base + off["pre"], base + off["act"], x3.data_ptr()
+    a.pre, a.act, a.x3 = (base + off["pre"]) if keep_pre else 0, base + off["act"], x3.data_ptr()
     a.mean1, a.rstd1, a.mean2, a.rstd2 = base + off["mean1"], base + off["rstd1"], base + off["mean2"], base + off["rstd2"]
     a.stats = base + off["stats"]
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -273,7 +273,7 @@ def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_ma
     return (dx, g.get("dln1_w"), g.get("dln1_b"),
             pick(dwqkv, 0, need[3]), pick(dbqkv, 0, need[4]), pick(dwqkv, 1, need[5]), pick(dbqkv, 1, need[6]),
             pick(dwqkv, 2, need[7]), pick(dbqkv, 2, need[8]), gw("dwo", (D, D)), g.get("dbo"), g.get("dln2_w"), g.get("dln2_b"),
-            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None)
+            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ encoder layer
@@ -284,7 +284,8 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2,
-                B: int, S: int, heads: int, size: Optional[Tuple[int, int, int]], pad_mask: Optional[torch.Tensor]):
+                B: int, S: int, heads: int, size: Optional[Tuple[int, int, int]], pad_mask: Optional[torch.Tensor],
+                training: bool = True):
         dt = x.dtype
         rows, D = x.shape
         Dff = w1.shape[0]
@@ -297,7 +298,8 @@ class EncoderLayerFn(torch.autograd.Function):
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
         if LAYER_CALLS and x.is_contiguous():
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
-            x3, arena = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask)
+            x3, arena = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask,
+                                          keep_pre=training)
             ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask)
             ctx.plan = plan
             return x3
@@ -308,12 +310,13 @@ class EncoderLayerFn(torch.autograd.Function):
         attn_o, stats = H.attn_fwd(qkv, B, S, heads, size=size, pad_mask=pad_mask)
         x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x)
         h2, mean2, rstd2 = H.layernorm_fwd(x2, ln2_w, ln2_b, rows, D)
-        pre = torch.empty((rows, Dff), dtype=dt, device=x.device)
+        pre = torch.empty((rows, Dff), dtype=dt, device=x.device) if training else None
         act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre)
         x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2)
 
-        ctx.save_for_backward(x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
-                              Wqkv, Wo, W1, W2, pad_mask)
+        if training:
+            ctx.save_for_backward(x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
+                                  Wqkv, Wo, W1, W2, pad_mask)
         ctx.meta = (B, S, heads, size, q_scale, D, Dff)
         return x3
 
@@ -363,7 +366,7 @@ class EncoderLayerFn(torch.autograd.Function):
         defer.flush()
         keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
         return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),
-                keep(12, dln2_b), dw1, db1, dw2, db2, None, None, None, None, None)
+                keep(12, dln2_b), dw1, db1, dw2, db2, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ embeddings
@@ -542,4 +545,5 @@ def encoder_layer(x, layer, B, S, heads, size, pad_mask):
         x, layer.layer_norm1.weight, layer.layer_norm1.bias,
         a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight, a.v_proj.bias,
         a.out_proj.weight, a.out_proj.bias, layer.layer_norm2.weight, layer.layer_norm2.bias,
-        m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, B, S, heads, size, pad_mask)
+        m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, B, S, heads, size, pad_mask,
+        torch.is_grad_enabled())       # forward-only passes (torch.no_grad: retrieval / inference) skip the MLP pre-activation

@@ -87,7 +87,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     d.scale, d.scale_cols = float(scale), scale_cols
     d.resid = 0 if resid is None else _chk(resid, "resid", A.dtype).data_ptr()
     d.ldr = ldr if ldr is not None else N
-    d.aux = 0 if aux is None else _chk(aux, "aux", out_dtype).data_ptr()
+    d.aux = 0 if aux is None else _chk(aux, "aux", out_dtype).data_ptr()       # BIAS_GELU without aux: forward-only
     d.ldaux = ldaux if ldaux is not None else N
     d.tab1 = 0 if tab1 is None else _chk(tab1, "tab1", torch.float32).data_ptr()
     d.tab2 = 0 if tab2 is None else _chk(tab2, "tab2", torch.float32).data_ptr()
