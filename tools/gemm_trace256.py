@@ -25,7 +25,20 @@ for name, N, K in [("out", 768, 768), ("fc1", 3072, 768), ("k1536", 768, 1536), 
     L.lib().xp_debug_set_gemm_trace(C.c_void_p(0))
     t = buf.cpu().tolist()
     res[name] = (t[1], t[2] - t[0], t[3] - t[2])
-    print(f"== {name}: nk={t[1]} loop={t[2]-t[0]} ticks epilogue={t[3]-t[2]} ticks")
+    # the same launch timed from outside (HIP events, 20 back-to-back launches): the difference to the traced workgroup's own
+    # lifetime x rounds is the per-launch fixed cost (dispatch, cold start, kernel-boundary L2 write-back, tail)
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(20):
+        H.gemm(A, W, M, N, K, out=out, epilogue=L.EPI_BIAS, bias=bias)
+    en.record(); torch.cuda.synchronize()
+    us = st.elapsed_time(en) / 20 * 1e3
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    rounds = -(-tiles // 256)
+    life = t[3] - t[0]
+    print(f"== {name}: nk={t[1]} loop={t[2]-t[0]} ticks epilogue={t[3]-t[2]} ticks | workgroup lifetime {life} shader cycles x {rounds} "
+          f"round(s) ({tiles} tiles) in {us:.1f} us per launch (HIP events) -> >= {life * rounds / us / 1e3:.2f} GHz shader clock")
 (n1, l1, _), (n2, l2, _) = res["fc1"], res["fc2"]
 per = (l2 - l1) / (n2 - n1)
-print(f"per k-tile {per:.1f} ticks; prologue+drain {l1 - n1 * per:.1f} ticks (s_memtime: 100 MHz constant clock -> x24 for 2.4 GHz cycles)")
+print(f"per k-tile {per:.1f} ticks; prologue+drain {l1 - n1 * per:.1f} ticks (s_memtime tick = one shader cycle: ticks / measured "
+      "time is the shader clock the kernel actually ran at)")
