@@ -74,9 +74,11 @@ def test_reduce_rows_batch_and_deferred_producers():
         mean, rstd = x.float().mean(1), 1.0 / x.float().var(1, unbiased=False).add(1e-5).sqrt()
         d = H.DeferredReduce(X.device)
         cs = H.colsum_deferred(X, rows, cols, d)
-        dx1, dg1, db1 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, defer=d)
+        dx1, dg1, db1 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, defer=d, name="ln_a")
         dres = torch.randn(rows, cols, device="cuda").to(dtype)
-        dx2, dg2, db2, dxs = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, dres=dres, defer=d, dx_colsum=True)
+        dx2, dg2, db2, dxs = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, dres=dres, defer=d, dx_colsum=True, name="ln_b")
+        with pytest.raises(RuntimeError, match="two producers"):      # slots are named: a second producer of a name cannot alias
+            H.colsum_deferred(X, rows, cols, d)
         d.flush()
         assert report(f"ln dx colsum {dtype}", dxs, dx2.double().sum(0), 3e-3 if dtype == torch.bfloat16 else 1e-5) <= 3e-3
         assert report(f"ln dgamma (3-vector partials) {dtype}", dg2, dg1, 2e-6) <= 2e-6

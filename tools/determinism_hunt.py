@@ -124,8 +124,8 @@ def install(rec):
     # colsum_deferred: its output is final only after flush
     orig_cd = H.colsum_deferred
 
-    def cd(X, rows, cols, defer, ldx=None):
-        out = orig_cd(X, rows, cols, defer, ldx=ldx)
+    def cd(X, rows, cols, defer, ldx=None, name="colsum"):
+        out = orig_cd(X, rows, cols, defer, ldx=ldx, name=name)
         rec.add("colsum_deferred", [out], {out.data_ptr()})
         return out
     H.colsum_deferred = cd

@@ -33,6 +33,7 @@
 #include "common.h"
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -333,12 +334,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
 
 template <bool AKS, bool BKS>
 void launch_one(const KParams& kp, dim3 grid, hipStream_t st) {
-  static bool configured = false;
   auto kern = gemm256_kernel<AKS, BKS>;
-  if (!configured) {
+  static std::once_flag configured;            // (forward thread and autograd thread may both arrive first)
+  std::call_once(configured, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    configured = true;
-  }
+  });
   kern<<<grid, NTH, LDS_BYTES, st>>>(kp);
 }
 

@@ -337,16 +337,17 @@ class EncoderLayerFn(torch.autograd.Function):
         # forward's argument list -- 1,2 ln1 | 3..8 q,k,v | 9,10 out_proj | 11,12 ln2 | 13,14 fc1 | 15,16 fc2
         need = ctx.needs_input_grad
         if need[14]:
-            dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre, colsum_defer=defer)
+            dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre, colsum_defer=defer,
+                                  colsum_name="db1")
         else:
             dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre), None
         dw2 = _wgrad(dx3, act, rows, D, Dff) if need[15] else None
-        db2 = H.colsum_deferred(dx3, rows, D, defer) if need[16] else None
+        db2 = H.colsum_deferred(dx3, rows, D, defer, name="db2") if need[16] else None
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
         dw1 = _wgrad(dpre, h2, rows, Dff, D) if need[13] else None
         # out_proj's bias gradient = column sums of dx2: accumulated by the LayerNorm backward that writes dx2
         dx2, dln2_w, dln2_b, dbo = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
-                                                   dx_colsum=True)
+                                                   dx_colsum=True, name="ln2")
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
         dwo = _wgrad(dx2, attn_o, rows, D, D) if need[9] else None
@@ -358,11 +359,11 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             dwq = dwk = dwv = None
         if need[4] or need[6] or need[8]:
-            dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer)
+            dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer, name="dbqkv")
             dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
         else:
             dbq = dbk = dbv = None
-        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer)
+        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer, name="ln1")
         defer.flush()
         keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
         return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),

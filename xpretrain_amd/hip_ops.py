@@ -59,7 +59,7 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
          a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
          scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
-         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None):
+         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None, colsum_name="gemm_colsum"):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc.
 
     ``colsum_defer`` (a DeferredReduce): also return the column sums of C (a bias gradient), as ``(C, colsum)``; the
@@ -98,9 +98,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     nrows = L.lib().xp_gemm_colsum_rows(C.byref(d))
     if nrows == 0:
         L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
-        return out, colsum_deferred(out, M, N, colsum_defer, ldx=d.ldc)
+        return out, colsum_deferred(out, M, N, colsum_defer, ldx=d.ldc, name=colsum_name)
     cs = torch.empty(N, dtype=torch.float32, device=A.device)
-    part = colsum_defer.slot(nrows * N * 4)
+    part = colsum_defer.slot(nrows * N * 4, colsum_name)
     d.colsum_partials = part.data_ptr()
     L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
     colsum_defer.add(part, 0, cs, nrows, N, N)
@@ -150,6 +150,7 @@ class DeferredReduce:
         self.device = device
         self.segs = []
         self._keep = []
+        self._names = set()
 
     def add(self, part: torch.Tensor, part_offset: int, out: torch.Tensor, nrows: int, width: int, stride: int,
             accumulate=False):
@@ -160,8 +161,13 @@ class DeferredReduce:
         self.segs.append(sg)
         self._keep.append((part, out))
 
-    def slot(self, nbytes: int) -> torch.Tensor:
-        return workspace(nbytes, self.device, f"defer{len(self._keep)}")
+    def slot(self, nbytes: int, name: str) -> torch.Tensor:
+        """partial-row buffer of the producer called `name` (one slot per producer NAME: reordering the producers of a
+        layer cannot alias two live partial buffers)"""
+        if name in self._names:
+            raise RuntimeError(f"DeferredReduce: two producers named {name!r} before flush()")
+        self._names.add(name)
+        return workspace(nbytes, self.device, "defer:" + name)
 
     def flush(self):
         if not self.segs:
@@ -173,15 +179,15 @@ class DeferredReduce:
             nb = lib.xp_reduce_rows_batch_workspace_bytes(arr, len(chunk))
             ws = workspace(nb, self.device, "reduce_batch")
             L.check(lib.xp_reduce_rows_batch(arr, len(chunk), _p(ws), ws.numel(), _stream()), "xp_reduce_rows_batch")
-        self.segs, self._keep = [], []
+        self.segs, self._keep, self._names = [], [], set()
 
 
-def colsum_deferred(X: torch.Tensor, rows: int, cols: int, defer: DeferredReduce, ldx=None) -> torch.Tensor:
+def colsum_deferred(X: torch.Tensor, rows: int, cols: int, defer: DeferredReduce, ldx=None, name="colsum") -> torch.Tensor:
     """Bias gradient whose final reduction is finished by ``defer.flush()``."""
     _chk(X, "X")
     out = torch.empty(cols, dtype=torch.float32, device=X.device)
     chunks = L.lib().xp_colsum_partial_rows(rows, cols)
-    part = defer.slot(chunks * cols * 4)
+    part = defer.slot(chunks * cols * 4, name)
     L.check(L.lib().xp_colsum_partials(_p(X), rows, cols, ldx or cols, _dt(X), _p(part), part.numel(), _stream()),
             "xp_colsum_partials")
     defer.add(part, 0, out, chunks, cols, cols)
@@ -201,7 +207,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, dres=None, dx=None, lddx=None,
-                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None, dx_colsum=False):
+                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None, dx_colsum=False, name="ln"):
     """Returns (dx, dgamma, dbeta) -- plus colsum(dx) when ``dx_colsum`` (deferred mode only)."""
     _chk(dy, "dy"); _chk(x, "x", dy.dtype)
     dx = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device) if dx is None else dx
@@ -209,7 +215,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, 
     dbeta = torch.empty(cols, dtype=torch.float32, device=dy.device) if dbeta is None else dbeta
     nb = L.lib().xp_layernorm_bwd_workspace_bytes(rows, cols)
     if defer is not None:     # parameter-gradient partial rows stay in their own slot until defer.flush()
-        ws = defer.slot(nb)
+        ws = defer.slot(nb, name)
         L.check(L.lib().xp_layernorm_bwd_partials(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
                                                   _p(dres), cols, _p(dx), lddx or cols, int(dx_colsum), rows, cols,
                                                   _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd_partials")
