@@ -93,6 +93,21 @@ def make_victims(dev):
         L.check(L.lib().xp_probe_pk_f32(err.data_ptr(), 2000, 2048, 12345, torch.cuda.current_stream().cuda_stream), "xp_probe_pk_f32")
         return [err]
 
+    # the text tower's GEMMs (128x128 family, 64 KiB LDS: they CAN share a CU with the 52 KiB attention workgroups of the
+    # video tower, unlike the 128 KiB 256x256 family) -- forward epilogues, dX, dW
+    Rt, Dt, Dft = 256, 512, 2048
+    xt = rn(Rt, Dt).to(BF); Wt1 = rn(Dft, Dt, sc=0.02).to(BF); Wt2 = rn(Dt, Dft, sc=0.02).to(BF); bt = 0.1 * rn(Dft)
+    Wtq = rn(3 * Dt, Dt, sc=0.02).to(BF); btq = 0.1 * rn(3 * Dt); dyt = rn(Rt, Dft, sc=1e-3).to(BF); bt2 = 0.1 * rn(Dt)
+
+    def text_gemms():
+        aux = torch.empty(Rt, Dft, dtype=BF, device=dev)
+        a = H.gemm(xt, Wt1, Rt, Dft, Dt, epilogue=L.EPI_BIAS_GELU, bias=bt, aux=aux)
+        b = H.gemm(a, Wt2, Rt, Dt, Dft, epilogue=L.EPI_BIAS_RESID, bias=bt2, resid=xt)
+        c = H.gemm(xt, Wtq, Rt, 3 * Dt, Dt, epilogue=L.EPI_BIAS_QSCALE, bias=btq, scale=0.125, scale_cols=Dt)
+        d = H.gemm(dyt, Wt1, Rt, Dt, Dft, b_kstrided=True)
+        e = H.gemm(dyt, xt, Dft, Dt, Rt, a_kstrided=True, b_kstrided=True, lda=Dft, ldb=Dt, out_dtype=torch.float32)
+        return [a, aux, b, c, d, e]
+
     def gemm_then_ln():     # the producer / consumer pair as in the layer backward
         dh = H.gemm(dpre, W1, ROWS, D, DFF, b_kstrided=True)
         d = H.DeferredReduce(dev)
@@ -169,6 +184,15 @@ def make_aggressors(dev):
     def attn_text_bwd():
         H.attn_bwd(qkv, ao, ao, st, 8, 32, 8, pad_mask=mask, q_scale=0.125)
 
+    qkv_v = rn(ROWS, 3 * D, sc=0.5).to(BF)
+    ao_v, st_v = H.attn_fwd(qkv_v, B, S, HEADS, size=SIZE)
+
+    def attn_vision():           # 52 KiB LDS workgroups, MFMA: can share a CU with the 64 KiB 128x128 GEMM family
+        H.attn_fwd(qkv_v, B, S, HEADS, size=SIZE)
+
+    def attn_vision_bwd():
+        H.attn_bwd(qkv_v, ao_v, ao_v, st_v, B, S, HEADS, size=SIZE, q_scale=0.125)
+
     def colsum_text():
         H.colsum(dpre, R, Dff)
 
@@ -184,7 +208,7 @@ def make_aggressors(dev):
     return {k: v for k, v in locals().items() if callable(v) and k not in ("rn",)}
 
 
-PK_VARIANTS = 14
+PK_VARIANTS = 15
 
 
 def run_pair(victim, agg, side, iters, agg_per_iter=4):

@@ -36,8 +36,8 @@ __global__ void probe_tr16_kernel(const unsigned short* in, const int* off, i16x
 //   6: v_pk_fma_f32 x, m, x                   7: v_pk_mul_f32 x, m
 //   8: v_pk_add_f32 op_sel:[0,1] (no neg)     9: v_pk_mul_f32 op_sel:[0,1]      10: v_pk_fma_f32 x, m, x op_sel:[1,0,0]
 //  11: v_pk_add_f32 op_sel:[1,0]             12: v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (halves of m swapped)
-//  13: v_pk_mul_f32 op_sel_hi:[0,1]
-constexpr int PK_VARIANTS = 14;
+//  13: v_pk_mul_f32 op_sel_hi:[0,1]              14: v_pk_mov_b32 x, m op_sel:[1,0]  (the form in the GEMM epilogues)
+constexpr int PK_VARIANTS = 15;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 template <int V>
 __device__ __forceinline__ void pk_variant(f32x2 x, f32x2 m, f32x2& r, float& e0, float& e1) {
@@ -67,6 +67,8 @@ __device__ __forceinline__ void pk_variant(f32x2 x, f32x2 m, f32x2& r, float& e0
     asm volatile("v_add_f32 %0, %3, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
   if constexpr (V == 12) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(r) : "v"(x), "v"(m));
     asm volatile("v_add_f32 %0, %2, %5\n\tv_add_f32 %1, %3, %4" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
+  if constexpr (V == 14) { asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=&v"(r) : "v"(x), "v"(m));
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(e0), "=&v"(e1) : "v"(x[1]), "v"(m[0])); }   // D.hi = op_sel[1] ? S1.hi : S1.lo
   if constexpr (V == 13) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=&v"(r) : "v"(x), "v"(m));
     asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %2, %5" : "=&v"(e0), "=&v"(e1) : "v"(x[0]), "v"(x[1]), "v"(m[0]), "v"(m[1])); }
 }
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void probe_pk_kernel(unsigned* err, int iters,
   pk_run<0>(err, iters, s, lane); pk_run<1>(err, iters, s + 1, lane); pk_run<2>(err, iters, s + 2, lane); pk_run<3>(err, iters, s + 3, lane);
   pk_run<4>(err, iters, s + 4, lane); pk_run<5>(err, iters, s + 5, lane); pk_run<6>(err, iters, s + 6, lane); pk_run<7>(err, iters, s + 7, lane);
   pk_run<8>(err, iters, s + 8, lane); pk_run<9>(err, iters, s + 9, lane); pk_run<10>(err, iters, s + 10, lane); pk_run<11>(err, iters, s + 11, lane);
-  pk_run<12>(err, iters, s + 12, lane); pk_run<13>(err, iters, s + 13, lane);
+  pk_run<12>(err, iters, s + 12, lane); pk_run<13>(err, iters, s + 13, lane); pk_run<14>(err, iters, s + 14, lane);
 }
 
 }  // namespace
