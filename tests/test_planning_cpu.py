@@ -72,3 +72,40 @@ def test_partial_row_counts_and_workspaces():
     assert lib.xp_attn_workspace_bytes(L.ATTN_CAUSAL, 8, 8, 0, 1, 32) == 8 * 8 * 32 * 4
     assert lib.xp_nce_loss_workspace_bytes(64, 512) >= 2 * 64 * 64 * 4
     assert lib.xp_vsc_fc_loss_workspace_bytes(64, 512) >= 6 * 64 * 64 * 4
+
+
+def _dims(rows, D, Dff, B, S, heads, size, dtype=L.XP_BF16):
+    d = L.XpLayerDims()
+    d.rows, d.D, d.Dff, d.B, d.S, d.heads = rows, D, Dff, B, S, heads
+    d.M, d.N, d.L = size if size else (0, 1, S)
+    d.attn_mode = L.ATTN_PROXY if size else L.ATTN_CAUSAL
+    d.dtype, d.q_scale, d.ln_eps = dtype, 0.125, 1e-5
+    return d
+
+
+def test_encoder_layer_workspace_planning():
+    """xp_encoder_layer_{fwd,bwd}_workspace_bytes (csrc/layer.hip): the backward workspace holds the six activation-gradient
+    temporaries, the largest split-K slab set, the deferred partial rows, the reduce scratch and the attention workspace."""
+    lib = L.lib()
+    d = _dims(8 * 2356, 768, 3072, 8, 2356, 12, (4, 12, 196))
+    fwd, bwd = lib.xp_encoder_layer_fwd_workspace_bytes(C.byref(d)), lib.xp_encoder_layer_bwd_workspace_bytes(C.byref(d))
+    rows, D, Dff = 8 * 2356, 768, 3072
+    temporaries = rows * (Dff + 4 * D + 3 * D) * 2
+    slabs = 7 * 3072 * 768 * 4                                     # fc1 / fc2 dW: split-K 7 (test above)
+    assert fwd >= lib.xp_attn_workspace_bytes(L.ATTN_PROXY, 8, 12, 4, 12, 196)
+    assert temporaries + slabs < bwd < temporaries + slabs + (64 << 20)
+    # text tower shape, fp32 mode: still consistent, and empty dims give 0
+    t = _dims(8 * 32, 512, 2048, 8, 32, 8, None, L.XP_F32)
+    assert lib.xp_encoder_layer_bwd_workspace_bytes(C.byref(t)) > 8 * 32 * (2048 + 7 * 512) * 4
+    z = _dims(0, 512, 2048, 8, 32, 8, None)
+    assert lib.xp_encoder_layer_bwd_workspace_bytes(C.byref(z)) == 0
+
+
+def test_encoder_layer_rejects_bad_arguments():
+    lib = L.lib()
+    a = L.XpLayerFwd()
+    a.dims = _dims(100, 768, 3072, 8, 2356, 12, (4, 12, 196))       # rows != B*S
+    assert lib.xp_encoder_layer_fwd(C.byref(a), None) != 0 and b"rows" in lib.xp_last_error()
+    b = L.XpLayerBwd()
+    b.dims = _dims(8 * 32, 512, 2048, 8, 32, 8, None)
+    assert lib.xp_encoder_layer_bwd(C.byref(b), None) != 0 and b"null pointer" in lib.xp_last_error()
