@@ -492,7 +492,7 @@ class CLIPModel(CLIPPreTrainedModel):
         return self._finish(image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict,
                             output_hidden_states)
 
-    overlap_text_tower = True
+    overlap_text_tower = os.environ.get("XPRETRAIN_OVERLAP_TEXT", "1") != "0"     # A/B switch (tools/)
     _side = None
 
     def _text_stream(self, device):
