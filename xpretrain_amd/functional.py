@@ -539,12 +539,19 @@ class VscFcLossFn(torch.autograd.Function):
         return tuple(t * g for t in ctx.saved_tensors)
 
 
+def _layer_params(layer):
+    """the 16 parameters of a CLIPEncoderLayer in EncoderLayerFn's argument order.  The sub-module handles are cached on the layer
+    (nn.Module.__getattr__ chains cost ~10 us per call otherwise); the Parameter objects are read from the modules' own tables
+    every time, so a replaced Parameter is always seen."""
+    mods = layer.__dict__.get("_xp_mods")
+    if mods is None or mods[7] is not layer.mlp.fc2._parameters or mods[1] is not layer.self_attn.q_proj._parameters:
+        a, m = layer.self_attn, layer.mlp
+        mods = layer.__dict__["_xp_mods"] = tuple(x._parameters for x in (layer.layer_norm1, a.q_proj, a.k_proj, a.v_proj, a.out_proj,
+                                                                            layer.layer_norm2, m.fc1, m.fc2))
+    return tuple(d[k] for d in mods for k in ("weight", "bias"))
+
+
 def encoder_layer(x, layer, B, S, heads, size, pad_mask):
     """Apply ``EncoderLayerFn`` with the parameters of a ``CLIPEncoderLayer`` module."""
-    a, m = layer.self_attn, layer.mlp
-    return EncoderLayerFn.apply(
-        x, layer.layer_norm1.weight, layer.layer_norm1.bias,
-        a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight, a.v_proj.bias,
-        a.out_proj.weight, a.out_proj.bias, layer.layer_norm2.weight, layer.layer_norm2.bias,
-        m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, B, S, heads, size, pad_mask,
-        torch.is_grad_enabled())       # forward-only passes (torch.no_grad: retrieval / inference) skip the MLP pre-activation
+    # last argument: forward-only passes (torch.no_grad: retrieval / inference) skip the MLP pre-activation
+    return EncoderLayerFn.apply(x, *_layer_params(layer), B, S, heads, size, pad_mask, torch.is_grad_enabled())

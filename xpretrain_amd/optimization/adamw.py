@@ -80,7 +80,9 @@ class AdamW(Optimizer):
                                  n_chunks=len(cmap) // 2, chunk_base=n_total_chunks,
                                  grads=(C.c_void_p * len(part))(), grp=(C.c_uint8 * len(part))()))
             n_total_chunks += len(cmap) // 2
-        return dict(key=self._plan_key(act, cache), launches=launches, n_chunks=n_total_chunks, entries=entries,
+        return dict(key=self._plan_key(act, cache), sig=[(gi, p, p.data_ptr(), self.state[p], self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                         for gi, p in act], sv=cache.structure_version,
+                    launches=launches, n_chunks=n_total_chunks, entries=entries,
                     partials=torch.empty(n_total_chunks, dtype=torch.float32, device=dev),
                     norm=torch.zeros((), dtype=torch.float32, device=dev))
 
@@ -102,15 +104,21 @@ class AdamW(Optimizer):
         if not act:
             return loss
         from ..functional import WEIGHTS
-        for _, p in act:                     # state initialisation (adamw.py:62-68) before the plan key looks at it
-            st = self.state[p]
-            if len(st) == 0:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p.data)
-                st["exp_avg_sq"] = torch.zeros_like(p.data)
-        if self._plan is None or self._plan["key"] != self._plan_key(act, WEIGHTS):
-            self._plan = self._build_plan(act, WEIGHTS)
         plan = self._plan
+        # steady state: the same parameters and moment tensors with the same storage as when the plan was built, and no change in the
+        # weight cache's buffers (the same facts _plan_key() hashes, checked without building the key)
+        if not (plan is not None and plan["sv"] == WEIGHTS.structure_version and len(act) == len(plan["sig"])
+                and all(a[1] is s[1] and a[0] == s[0] and a[1].data_ptr() == s[2] and s[3]["exp_avg"].data_ptr() == s[4]
+                        and s[3]["exp_avg_sq"].data_ptr() == s[5] for a, s in zip(act, plan["sig"]))):
+            for _, p in act:                 # state initialisation (adamw.py:62-68) before the plan key looks at it
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+            if plan is None or plan["key"] != self._plan_key(act, WEIGHTS):
+                self._plan = self._build_plan(act, WEIGHTS)
+            plan = self._plan
         clip = max_grad_norm is not None and max_grad_norm > 0
         stream = H._stream()
         lib = L.lib()
@@ -153,6 +161,14 @@ class AdamW(Optimizer):
         self.last_grad_norm = plan["norm"] if clip else None
         self._wrote = plan["entries"]
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plan = None                # the moment tensors were replaced
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._plan = None
 
     def clip_and_step(self, max_norm):
         """``clip_grad_norm_(params, max_norm)`` + ``step()`` in one pass; returns the (device) gradient norm."""
