@@ -2,7 +2,9 @@
 """Headline benchmark: CLIP-ViP video-text contrastive training step on MI355X (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+    (N>1: the script starts its own N ranks -- `python bench.py --gpus 8` re-executes itself under torch.distributed.run
+     with one process per GPU on 127.0.0.1; under an external launcher -- python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ..., WORLD_SIZE set -- it just joins the group)
 
 One "step" = clamp logit_scale -> VidCLIP.forward (ViT-B/16 video tower with video-proxy tokens + CLIP text
 tower) -> packed all-gather of features (N>1) -> NCELearnableTempLoss -> backward -> bucketed gradient
@@ -70,6 +72,8 @@ def parse():
                     "(works; measured 23.3 vs 23.1 ms/step eager on MI355X -- the step is GPU-bound and replaying a "
                     "600-node multi-stream graph costs the host as much as the eager launches); 0 (default): eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, join the process group, print the world size "
+                    "measured by a collective and exit (no GPU work; backend gloo when there is no GPU) -- the launcher self-test")
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     return ap.parse_args()
 
@@ -183,12 +187,41 @@ def workload_tag(a, W):
     return "custom shape"
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` (one rank per GPU; the reference is started as
+    `horovodrun -np $NUM_GPUS python src/pretrain/run_pretrain.py`, CLIP-ViP/README.md:58).  Does not return."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)
     from xpretrain_amd import distributed as D
     local_rank = D.init_from_env()
     W, rank = D.world_size(), D.rank()
-    assert W == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={W}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if W != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={W} ranks")
+    n_seen = D.ranks_seen()
+    if a.launch_check:
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "world_size": W, "n_ranks_seen": n_seen,
+                              "backend": torch.distributed.get_backend() if W > 1 else None}), flush=True)
+        if W > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -266,11 +299,14 @@ def main():
         for _ in range(2):
             loss = step()
         sync()
+    c_proc0, c_main0 = time.process_time(), time.thread_time()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
-    t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (no sync): launch-bound if ~= dt
-    sync()
+    t_enq = time.perf_counter() - t0          # WALL time until the last launch is queued: includes any back-pressure of the
+    #                                           runtime's queues once the host runs ahead, so it is not a cost
+    c_proc, c_main = time.process_time() - c_proc0, time.thread_time() - c_main0   # CPU seconds: all threads (forward thread +
+    sync()                                    # autograd thread + runtime helpers) / the forward thread alone, before the sync
     dt = time.perf_counter() - t0
     if W > 1:
         t = torch.tensor([dt], device=dev)
@@ -303,6 +339,7 @@ def main():
         tr_b, note_b = pmc_traffic("SS_dw1") if full else (None, "PMC summary exists for the cfg #2 shape only")
         res = {
             "metric": "video-text pairs/sec", "value": round(pairs_s, 3), "unit": "pairs/s", "n_gpus": W,
+            "n_ranks_seen": n_seen,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"CLIP-ViP ViT-B/{a.patch} video-text contrastive train step (fwd+loss+bwd+grad-sync+"
@@ -312,7 +349,9 @@ def main():
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager"},
             "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
             "step_frac_of_bf16_peak": round(step_flops / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
+            "host_cpu_ms_per_step": round(c_proc / a.steps * 1e3, 3),              # CPU time of ALL host threads per step
+            "host_main_thread_cpu_ms_per_step": round(c_main / a.steps * 1e3, 3),  # forward + optimizer thread alone
+            "host_enqueue_wall_ms_per_step": round(t_enq / a.steps * 1e3, 3),      # wall incl. queue back-pressure; not a cost
             "vit_forward_ms": round(vit_fwd_ms, 3),
             "vit_forward_frac_of_bf16_peak": round(f_vis * a.batch / (vit_fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             # dominant forward kernel; algorithmic bytes = A + W + two bf16 outputs

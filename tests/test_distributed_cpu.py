@@ -98,3 +98,77 @@ def test_single_process_passthrough():
     a, b = torch.randn(2, 4), torch.randn(2, 4)
     ga, gb = D.gather_features(a, b)
     assert ga is a and gb is b and D.world_size() == 1 and D.rank() == 0
+
+
+# ---------------------------------------------------------------------------------------------- resume: optimizer state
+def _resume_worker(rank, world, port, tmpdir, q):
+    """run_pretrain.py:231-232,269-291: only rank 0 finds a restore.pt (the other rank's directory is empty, standing for a
+    rank that read a different / no generation); after E2E_TrainingRestorer every rank must hold rank 0's step counter,
+    parameters and Adam moments."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import types
+    from xpretrain_amd import distributed as D
+    from xpretrain_amd.utils.load_save import E2E_TrainingRestorer
+    D.init_from_env("gloo")
+    torch.manual_seed(rank)                                   # different initial weights per rank on purpose
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    opt = torch.optim.AdamW([{"params": model[0].parameters(), "lr": 1e-2}, {"params": model[1].parameters(), "lr": 3e-3}])
+    out = os.path.join(tmpdir, f"rank{rank}")
+    os.makedirs(out, exist_ok=True)
+    opts = types.SimpleNamespace(output_dir=out, save_steps_ratio=0.5, num_train_steps=4)
+    if rank == 0:                                             # a previous run of rank 0: 3 steps, checkpoint at step 2
+        g = torch.Generator().manual_seed(5)
+        for _ in range(2):
+            opt.zero_grad()
+            model(torch.randn(4, 6, generator=g)).square().sum().backward()
+            opt.step()
+        from xpretrain_amd.utils import load_save as LS
+        torch.save({"global_step": 2, "model_state_dict": LS.to_cpu_half(model.state_dict()),
+                    "optim_state_dict": LS.to_cpu_half(opt.state_dict())}, os.path.join(out, "restore.pt"))
+        with torch.no_grad():                                 # the live objects drift away from the checkpoint again
+            for p in model.parameters():
+                p.add_(1.0)
+    dist.barrier()
+    r = E2E_TrainingRestorer(opts, model, opt)                # rank 0 restores from file, rank 1 finds nothing; then sync_ranks
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]
+                     + [opt.state[p][k].reshape(-1) for p in model.parameters() for k in ("exp_avg", "exp_avg_sq")]
+                     + [torch.tensor([float(opt.state[p]["step"]) for p in model.parameters()])])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered)
+    lrs = [g["lr"] for g in opt.param_groups]
+    q.put((rank, bool(same), r.global_step, lrs, float(flat.abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resume_broadcasts_optimizer_state(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res                       # identical parameters, Adam moments and step counts
+    assert [r[2] for r in res] == [2, 2], res                # both resume at rank 0's global_step
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4] and res[0][4] > 0, res
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run and both ranks join
+    the process group (gloo here: no GPU); --launch-check stops before any GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world_size"] == 2 and d["n_ranks_seen"] == 2 and d["n_gpus"] == 2, d

@@ -75,3 +75,26 @@ def test_no_cpu_fallback():
     video, ids, mask = O.synthetic_inputs(2, 2, 32, 8, vocab=120)
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(video, ids, mask)
+
+
+def test_output_objects_resolve_lazy_fields_everywhere():
+    """`attentions` exists (None, as in the reference), dict(out) / out.copy() / pickle never leak a thunk, and a
+    lazy field is evaluated under the grad mode of the forward that created it."""
+    import pickle
+    from xpretrain_amd.modeling.CLIP_ViP import BaseModelOutputWithPooling, _Lazy
+    w = torch.ones(2, requires_grad=True)
+    with torch.no_grad():
+        lazy = _Lazy(lambda: w * 2)
+    out = BaseModelOutputWithPooling(last_hidden_state=lazy, pooler_output=torch.zeros(1), hidden_states=None, attentions=None)
+    assert out.attentions is None and out.hidden_states is None
+    c = out.copy()
+    assert torch.is_tensor(dict.__getitem__(c, "last_hidden_state"))
+    assert not c.last_hidden_state.requires_grad                   # created under no_grad -> evaluated under no_grad
+    d = dict(out.items())
+    assert all(not isinstance(v, _Lazy) for v in d.values())
+    r = pickle.loads(pickle.dumps(BaseModelOutputWithPooling(last_hidden_state=_Lazy(lambda: torch.ones(3)), pooler_output=None,
+                                                             hidden_states=None, attentions=None)))
+    assert torch.equal(r.last_hidden_state, torch.ones(3))
+    assert out.to_tuple()[1] is out.pooler_output and len(out.to_tuple()) == 2
+    with pytest.raises(AttributeError):
+        out.no_such_field

@@ -45,16 +45,11 @@ def bench_gemm():
         dX = torch.empty(M, K, dtype=bf, device="cuda")
         us = timeit(lambda: H.gemm(dY, W, M, K, N, b_kstrided=True, out=dX))
         print(f"gemm dX  {name:4s}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
-        # dW[N,K] = dY^T X, split-K
-        import os
-        for split in tuple(int(x) for x in os.environ.get('SPLITS', '4,8,16').split(',')):
-            slabs = torch.empty(split, N, K, device="cuda")
-            dW = torch.empty(N, K, device="cuda")
-            def f():
-                H.gemm(dY, A, N, K, M, a_kstrided=True, b_kstrided=True, lda=N, ldb=K, split_k=split, out=slabs)
-                H.splitk_reduce(slabs, dW)
-            us = timeit(f)
-            print(f"gemm dW  {name:4s} split={split:2d}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
+        # dW[N,K] = dY^T X: the production path (functional._wgrad: split-K chosen by xp_gemm_auto_split + deterministic reduce)
+        from xpretrain_amd.functional import _wgrad, _split_for
+        split = _split_for(N, K, M, bf, (0, 0, 0))
+        us = timeit(lambda: _wgrad(dY, A, M, N, K))
+        print(f"gemm dW  {name:4s} split={split:2d} (auto): {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
         us = timeit(lambda: H.colsum(dY, M, N))
         print(f"colsum   {name:4s}: {us:8.1f} us  {M*N*2/us/1e3:7.1f} GB/s")
 

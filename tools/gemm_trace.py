@@ -22,7 +22,7 @@ for name, N, K in [("fc1", 3072, 768), ("fc2", 768, 3072)]:
     L.lib().xp_debug_set_gemm_trace(C.c_void_p(0))
     t = buf.cpu().tolist()
     nk = t[1]
-    print(f"== {name}: nk={nk} loop={t[2]-t[0]} cyc epilogue={t[3]-t[2]} cyc  (s_memtime ticks; 100 MHz ref clock if constant)")
+    print(f"== {name}: nk={nk} loop={t[2]-t[0]} cyc epilogue={t[3]-t[2]} cyc  (s_memtime ticks = shader cycles, profiles/r03a_clock_probe.txt)")
     import os
     g256 = os.environ.get("XPRETRAIN_GEMM256", "0") != "0"
     print(" kt  vmwait  barrier   issue  compute   total" if g256 else " kt   issue  compute  vmwait  barrier   total")

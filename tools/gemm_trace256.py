@@ -41,4 +41,4 @@ for name, N, K in [("out", 768, 768), ("fc1", 3072, 768), ("k1536", 768, 1536), 
 (n1, l1, _), (n2, l2, _) = res["fc1"], res["fc2"]
 per = (l2 - l1) / (n2 - n1)
 print(f"per k-tile {per:.1f} ticks; prologue+drain {l1 - n1 * per:.1f} ticks (s_memtime tick = one shader cycle: ticks / measured "
-      "time is the shader clock the kernel actually ran at)")
+      "time is the shader clock the kernel actually ran at; tools/clock_probe.hip pins 1 tick = 1 shader cycle with an MFMA ruler)")

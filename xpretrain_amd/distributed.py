@@ -11,7 +11,8 @@ utils/distributed.py) with three pieces designed for point-to-point xGMI rather 
   keep all 7 xGMI links busy); when a bucket's last gradient arrives its gradients are packed with one
   multi-tensor copy and the all-reduce is launched asynchronously, overlapping the rest of backward.
   ``average=True`` reproduces ``hvd.DistributedOptimizer`` (grads / world_size).
-* ``broadcast_parameters`` -- rank-0 -> all at start-up (hvd.broadcast_parameters, run_pretrain.py:231).
+* ``broadcast_parameters`` / ``broadcast_optimizer_state`` -- rank-0 -> all at start-up and after a ``restore.pt`` resume
+  (hvd.broadcast_parameters / hvd.broadcast_optimizer_state, run_pretrain.py:231-232).
 
 Everything is backend-agnostic (the CPU tests run it on ``gloo`` with world_size 2).
 """
@@ -190,8 +191,9 @@ class GradBucketReducer:
                 # the sources may have been produced (and allocated) on another stream: re-pointing .grad below drops
                 # their last reference, and the caching allocator would hand the block back to the PRODUCER stream's pool
                 # at once -- where ongoing backward work could overwrite it while this copy is still queued
-                for g in src:
-                    g.record_stream(cur)
+                for p, v in zip(b["params"], b["views"]):
+                    if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                        p.grad.record_stream(cur)      # the ORIGINAL gradient (a .float() temporary is already cur's)
         for p, v in zip(b["params"], b["views"]):
             p.grad = v
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
@@ -248,3 +250,78 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t, src)
+    from .functional import WEIGHTS          # the compute-dtype weight copies were made from the pre-broadcast values
+    WEIGHTS.invalidate()
+
+
+def broadcast_optimizer_state(optimizer: torch.optim.Optimizer, src: int = 0):
+    """``hvd.broadcast_optimizer_state(optimizer, root_rank=0)`` (run_pretrain.py:232): after this call every rank holds rank
+    ``src``'s optimizer state -- per-parameter tensors (``exp_avg`` / ``exp_avg_sq``), per-parameter scalars (``step``) and the
+    param-group hyper-parameters (``lr`` ...).  Needed after a resume: a rank whose restore differed (or that did not restore)
+    would otherwise step with its own Adam moments and silently diverge from step 1.  Parameters are matched by their
+    position in ``param_groups`` (as ``Optimizer.state_dict`` does); state entries missing on a receiving rank are created,
+    entries the source does not have are dropped.  Tensors travel packed per dtype in a few large broadcasts."""
+    if _single():
+        return
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    me = rank()
+    if me == src:
+        meta = {"groups": [{k: v for k, v in g.items() if k != "params"} for g in optimizer.param_groups], "state": []}
+        for p in params:
+            st = optimizer.state.get(p, {})
+            meta["state"].append({k: (("tensor", tuple(v.shape), str(v.dtype).replace("torch.", "")) if torch.is_tensor(v) else ("value", v))
+                                  for k, v in st.items()})
+        box = [meta]
+    else:
+        box = [None]
+    dist.broadcast_object_list(box, src)
+    meta = box[0]
+    if len(meta["groups"]) != len(optimizer.param_groups) or len(meta["state"]) != len(params):
+        raise RuntimeError("broadcast_optimizer_state: the optimizers of the ranks have different parameter groups")
+    for g, mg in zip(optimizer.param_groups, meta["groups"]):
+        g.update(mg)
+    by_dtype = {}
+    for p, ms in zip(params, meta["state"]):
+        st = optimizer.state[p] if ms else optimizer.state.get(p)
+        if not ms:
+            if st is not None:
+                optimizer.state.pop(p, None)
+            continue
+        for k in [k for k in st if k not in ms]:
+            del st[k]
+        for k, desc in ms.items():
+            if desc[0] == "value":
+                st[k] = desc[1]
+            else:
+                _, shape, dtype = desc
+                dtype = getattr(torch, dtype)
+                t = st.get(k)
+                if not torch.is_tensor(t) or tuple(t.shape) != shape or t.dtype != dtype or t.device != p.device or not t.is_contiguous():
+                    t = st[k] = torch.zeros(shape, dtype=dtype, device=p.device)
+                by_dtype.setdefault((dtype, p.device), []).append(t)
+    cap = 64 << 20
+    for (dtype, device), ts in by_dtype.items():
+        i = 0
+        while i < len(ts):
+            chunk, nbytes = [], 0
+            while i < len(ts) and (not chunk or nbytes + ts[i].numel() * ts[i].element_size() <= cap):
+                chunk.append(ts[i]); nbytes += ts[i].numel() * ts[i].element_size(); i += 1
+            flat = torch.cat([t.reshape(-1) for t in chunk]) if len(chunk) > 1 else chunk[0].reshape(-1)
+            dist.broadcast(flat, src)
+            if len(chunk) > 1 and me != src:
+                off = 0
+                for t in chunk:
+                    t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+    if hasattr(optimizer, "_plan"):
+        optimizer._plan = None        # optimization.AdamW caches moment addresses
+
+
+def ranks_seen() -> int:
+    """number of ranks that take part in the default group, measured by a collective (all-reduce of ones), not read from the
+    environment: what ``bench.py`` prints as ``n_ranks_seen``."""
+    if _single():
+        return 1
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    one = torch.ones((), dtype=torch.int32, device=dev)
+    dist.all_reduce(one)
+    return int(one.item())

@@ -217,6 +217,25 @@ def _layer_plan(rows, D, Dff, B, S, heads, size, dtype) -> _LayerPlan:
     return p
 
 
+def _native_ok(x, vecs, mats, pad_mask) -> bool:
+    """The native layer calls hand raw device pointers to C: everything the op-by-op path validates per call (hip_ops._chk)
+    is validated here in one place -- 1-D parameters contiguous fp32 on x's device, weight copies contiguous in the compute
+    dtype, an int64 contiguous padding mask.  False -> the caller takes the op-by-op path, whose checks raise a TypeError
+    that names the offending argument (a model cast with .bfloat16(), a bool mask, a strided parameter ...)."""
+    dev, dt = x.device, x.dtype
+    if not x.is_cuda or not x.is_contiguous():
+        return False
+    for v in vecs:
+        if v.dtype != torch.float32 or v.device != dev or not v.is_contiguous():
+            return False
+    for m in mats:
+        if m.dtype != dt or m.device != dev or not m.is_contiguous():
+            return False
+    if pad_mask is not None and (pad_mask.dtype != torch.int64 or pad_mask.device != dev or not pad_mask.is_contiguous()):
+        return False
+    return True
+
+
 def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True):
     dev = x.device
     arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
@@ -296,7 +315,7 @@ class EncoderLayerFn(torch.autograd.Function):
         Wqkv = WEIGHTS.fused((wq, wk, wv), dt)
         bqkv = WEIGHTS.fused((bq, bk, bv), torch.float32)
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
-        if LAYER_CALLS and x.is_contiguous():
+        if LAYER_CALLS and _native_ok(x, (ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2), (Wqkv, Wo, W1, W2), pad_mask):
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
             x3, arena = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask,
                                           keep_pre=training)
@@ -324,6 +343,9 @@ class EncoderLayerFn(torch.autograd.Function):
     def backward(ctx, dx3):
         if ctx.plan is not None:
             x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask = ctx.saved_tensors
+            if dx3.dtype != x.dtype or dx3.device != x.device or dx3.shape != x.shape:
+                raise TypeError(f"EncoderLayerFn.backward: incoming gradient is {dx3.dtype} {tuple(dx3.shape)} on {dx3.device}, "
+                                f"expected {x.dtype} {tuple(x.shape)} on {x.device}")
             return _layer_bwd_native(ctx, dx3.contiguous(), x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, ctx.plan)
         (x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
          Wqkv, Wo, W1, W2, pad_mask) = ctx.saved_tensors
@@ -543,12 +565,24 @@ def _layer_params(layer):
     """the 16 parameters of a CLIPEncoderLayer in EncoderLayerFn's argument order.  The sub-module handles are cached on the layer
     (nn.Module.__getattr__ chains cost ~10 us per call otherwise); the Parameter objects are read from the modules' own tables
     every time, so a replaced Parameter is always seen."""
-    mods = layer.__dict__.get("_xp_mods")
-    if mods is None or mods[7] is not layer.mlp.fc2._parameters or mods[1] is not layer.self_attn.q_proj._parameters:
+    cached = layer.__dict__.get("_xp_mods")
+    if cached is not None:
+        # all 8 sub-modules are re-checked by identity through plain dict lookups (nn.Module keeps children in _modules):
+        # module surgery on ANY of them (adapters, replaced LayerNorms ...) rebuilds the table
+        mods, tabs = cached
+        lm = layer._modules
+        a, m = lm["self_attn"]._modules, lm["mlp"]._modules
+        live = (lm["layer_norm1"], a["q_proj"], a["k_proj"], a["v_proj"], a["out_proj"], lm["layer_norm2"], m["fc1"], m["fc2"])
+        for x, y, t in zip(live, mods, tabs):
+            if x is not y or x._parameters is not t:
+                cached = None
+                break
+    if cached is None:
         a, m = layer.self_attn, layer.mlp
-        mods = layer.__dict__["_xp_mods"] = tuple(x._parameters for x in (layer.layer_norm1, a.q_proj, a.k_proj, a.v_proj, a.out_proj,
-                                                                            layer.layer_norm2, m.fc1, m.fc2))
-    return tuple(d[k] for d in mods for k in ("weight", "bias"))
+        mods = (layer.layer_norm1, a.q_proj, a.k_proj, a.v_proj, a.out_proj, layer.layer_norm2, m.fc1, m.fc2)
+        tabs = tuple(x._parameters for x in mods)
+        layer.__dict__["_xp_mods"] = (mods, tabs)
+    return tuple(d[k] for d in tabs for k in ("weight", "bias"))
 
 
 def encoder_layer(x, layer, B, S, heads, size, pad_mask):

@@ -48,7 +48,12 @@ class _Lazy:
     """a field that is cheap but not free and that the training step never reads: computed on first access"""
 
     def __init__(self, fn):
-        self.fn = fn
+        grad = torch.is_grad_enabled()            # evaluate under the grad mode of the forward that created the field,
+
+        def run():                                # not under whatever is current at access time
+            with torch.set_grad_enabled(grad):
+                return fn()
+        self.fn = run
 
 
 class _Output(dict):
@@ -77,6 +82,20 @@ class _Output(dict):
 
     def items(self):
         return [(k, self[k]) for k in self.keys()]
+
+    def _resolve_all(self):
+        for k in list(self.keys()):
+            self[k]
+        return self
+
+    def copy(self):                    # CPython's dict.copy / dict(out) / pickle bypass __getitem__: resolve first
+        return type(self)(**{k: self[k] for k in self.keys()})
+
+    def __reduce__(self):
+        return (type(self), (), None, None, iter(self._resolve_all().items()))
+
+    def to_tuple(self):
+        return tuple(v for v in self.values() if v is not None)
 
 
 class CLIPOutput(_Output):
@@ -251,8 +270,10 @@ class CLIPTextTransformer(nn.Module):
         ln = self.final_layer_norm
         pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias)
         last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D))      # (:772) resolved on access
-        return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled,
-                                          hidden_states=None if hs is None else tuple(h.view(B, Lt, D) for h in hs))
+        out = BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled,
+                                         hidden_states=None if hs is None else tuple(h.view(B, Lt, D) for h in hs),
+                                         attentions=None)
+        return out if return_dict is None or return_dict else out.to_tuple()
 
 
 class CLIPVisionTransformer(nn.Module):
@@ -281,8 +302,10 @@ class CLIPVisionTransformer(nn.Module):
         x = self.encoder(x, B, S, size, None, hs)
         pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
                                       self.post_layernorm.bias)
-        return BaseModelOutputWithPooling(last_hidden_state=x.view(B, S, D), pooler_output=pooled,
-                                          hidden_states=None if hs is None else tuple(h.view(B, S, D) for h in hs))
+        out = BaseModelOutputWithPooling(last_hidden_state=x.view(B, S, D), pooler_output=pooled,
+                                         hidden_states=None if hs is None else tuple(h.view(B, S, D) for h in hs),
+                                         attentions=None)
+        return out if return_dict is None or return_dict else out.to_tuple()
 
 
 # ------------------------------------------------------------------------------------------ models
@@ -507,6 +530,10 @@ class CLIPModel(CLIPPreTrainedModel):
         loss = None          # the reference returns None as well unless return_loss (:1160-1162)
         if return_loss:      # clip_loss (:70-73) == NCELearnableTempLoss / 2, through the fused HIP loss kernel
             loss = XF.NCELossFn.apply(image_embeds, text_embeds, self.logit_scale) * 0.5
-        return CLIPOutput(loss=loss, logits_per_image=logits_per_image, logits_per_text=logits_per_text,
-                          text_embeds=text_embeds, image_embeds=image_embeds, text_model_output=text_outputs,
-                          vision_model_output=vision_outputs)
+        out = CLIPOutput(loss=loss, logits_per_image=logits_per_image, logits_per_text=logits_per_text,
+                         text_embeds=text_embeds, image_embeds=image_embeds, text_model_output=text_outputs,
+                         vision_model_output=vision_outputs)
+        if return_dict is not None and not return_dict:      # the reference's tuple form (CLIP_ViP.py:1160-1162)
+            t = (out.logits_per_image, out.logits_per_text, text_embeds, image_embeds, text_outputs, vision_outputs)
+            return ((loss,) + t) if loss is not None else t
+        return out

@@ -108,7 +108,8 @@ class AdamW(Optimizer):
         # steady state: the same parameters and moment tensors with the same storage as when the plan was built, and no change in the
         # weight cache's buffers (the same facts _plan_key() hashes, checked without building the key)
         if not (plan is not None and plan["sv"] == WEIGHTS.structure_version and len(act) == len(plan["sig"])
-                and all(a[1] is s[1] and a[0] == s[0] and a[1].data_ptr() == s[2] and s[3]["exp_avg"].data_ptr() == s[4]
+                and all(a[1] is s[1] and a[0] == s[0] and a[1].data_ptr() == s[2] and self.state.get(a[1]) is s[3]
+                        and s[3]["exp_avg"].data_ptr() == s[4]
                         and s[3]["exp_avg_sq"].data_ptr() == s[5] for a, s in zip(act, plan["sig"]))):
             for _, p in act:                 # state initialisation (adamw.py:62-68) before the plan key looks at it
                 st = self.state[p]

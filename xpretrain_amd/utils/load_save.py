@@ -106,6 +106,21 @@ class E2E_TrainingRestorer:
         self.global_step = 0
         if os.path.exists(self.save_path) or os.path.exists(self.backup_path):
             _retry("E2E_TrainingRestorer.restore", self.restore)
+        self.sync_ranks()
+
+    def sync_ranks(self, src: int = 0):
+        """Data-parallel runs: after the (per-rank) restore every rank takes rank ``src``'s step counter, parameters AND
+        optimizer state (hvd.broadcast_parameters + hvd.broadcast_optimizer_state, run_pretrain.py:231-232) -- a rank that read
+        the backup generation, or found no file, must not continue with different Adam moments.  No-op in a 1-rank run."""
+        from .. import distributed as D
+        if D.world_size() == 1:
+            return
+        import torch.distributed as dist
+        box = [self.global_step]
+        dist.broadcast_object_list(box, src)
+        self.global_step = box[0]
+        D.broadcast_parameters(self.model, src)
+        D.broadcast_optimizer_state(self.optimizer, src)
 
     def step(self):
         self.global_step += 1
