@@ -71,7 +71,7 @@ typedef struct XpGemmDesc {
   const void* resid; int64_t ldr;       /* dtype = in_dtype                                        */
   void* aux; int64_t ldaux;             /* dtype = out_dtype                                       */
   const float* tab1; const float* tab2; int64_t tab_L;
-  /* optional: column sums of the FINISHED outputs (fp32, before rounding), one partial row per 128 output rows:
+  /* optional: column sums of the FINISHED outputs (fp32, before rounding), one partial row per half tile height of rows:
    * colsum_partials[r*N + n], r < xp_gemm_colsum_rows(desc).  This is the bias gradient of the Linear whose output
    * gradient this GEMM produces (autograd computes it as grad.sum(0), CLIP_ViP.py:383-396) without re-reading it.
    * Only where xp_gemm_colsum_rows() > 0 (large bf16 problems, EPI_NONE / EPI_GELU_BWD); finish with
@@ -89,6 +89,11 @@ int32_t xp_gemm_auto_split(const XpGemmDesc* desc);
 /* number of partial rows xp_gemm writes to desc->colsum_partials, or 0 if the fused column sums are not available
  * for this problem (desc->colsum_partials itself is ignored here) */
 int64_t xp_gemm_colsum_rows(const XpGemmDesc* desc);
+/* Output-tile height (rows) of the kernel family xp_gemm will run `desc` with: 256 / 224 for the 256-wide ping-pong family
+ * (the height is chosen per problem so that the tile count fills whole rounds of the 256 CUs: at CLIP-ViP's 18848 token
+ * rows, modeling/CLIP_ViP.py:341-343,379,393-395, 85 x {3,9,12} tiles of 224 rows instead of 74 x {3,9,12} of 256), 128 for
+ * the 128x128 family.  desc->split_k is honoured; the data pointers are ignored. */
+int32_t xp_gemm_tile_rows(const XpGemmDesc* desc);
 
 /* out[i] (+)= sum_z slabs[z*n + i], fp32; accumulate != 0 adds into out (gradient accumulation). */
 int xp_splitk_reduce(const float* slabs, float* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);

@@ -210,7 +210,7 @@ def test_gemm_fused_colsum(epi):
     defer = H.DeferredReduce(dY.device)
     kw = dict(epilogue=L.EPI_GELU_BWD, resid=pre) if epi == "gelu_bwd" else {}
     out, cs = H.gemm(dY, W, M, N, K, b_kstrided=True, colsum_defer=defer, **kw)
-    assert len(defer.segs) == 1 and defer.segs[0].nrows == 2 * ((M + 255) // 256)      # the fused path was taken
+    assert len(defer.segs) == 1 and defer.segs[0].nrows == 2 * ((M + 223) // 224)      # the fused path was taken (224-row tiles)
     defer.flush()
     ref = dY.double() @ W.double()
     if epi == "gelu_bwd":
@@ -222,3 +222,129 @@ def test_gemm_fused_colsum(epi):
     out2, cs2 = H.gemm(dY[:300].contiguous(), W, 300, N, K, b_kstrided=True, colsum_defer=defer, **({} if epi == "none" else dict(epilogue=L.EPI_GELU_BWD, resid=pre[:300].contiguous())))
     defer.flush()
     assert report(f"fallback colsum {epi}", cs2, out2.double().sum(0), 1e-5) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- 224-row tiles, direct epilogue
+def _tile_rows(M, N, K, b_kstrided=False, split_k=1, out_f32=False):
+    import ctypes as C
+    from xpretrain_amd import _lib as L
+    d = L.XpGemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr, d.ldaux = M, N, K, K, (N if b_kstrided else K), N, N, N
+    d.b_kstrided, d.in_dtype, d.out_dtype, d.split_k = int(b_kstrided), L.XP_BF16, (L.XP_F32 if out_f32 else L.XP_BF16), split_k
+    return int(L.lib().xp_gemm_tile_rows(C.byref(d)))
+
+
+def test_tile_height_is_chosen_per_shape():
+    """BASELINE cfg #2 token count: 85 tiles of 224 rows fill 1 / 3 / 4 rounds of the CUs (74 of 256 rows: 0.87 of them);
+    a multiple of 256 keeps 256-row tiles; small problems stay in the 128x128 family."""
+    assert _tile_rows(18848, 768, 768) == 224 and _tile_rows(18848, 2304, 768) == 224 and _tile_rows(18848, 3072, 768) == 224
+    assert _tile_rows(18848, 768, 3072, b_kstrided=True) == 224
+    assert _tile_rows(50208, 768, 768) == 224              # configs[3]/[4] token count
+    assert _tile_rows(16384, 1024, 512) == 256
+    assert _tile_rows(256, 512, 768) == 128
+
+
+@pytest.mark.parametrize("M", [18848, 18848 + 40, 18848 - 200])
+def test_gemm224_nt_all_epilogues(M):
+    """224-row tiles (second M half = 48 rows per wave, zero-filled to 64 in LDS) through every fused epilogue of the direct
+    (accumulator -> global, N-side rows permuted) store path; ragged last tile."""
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(M)
+    bf = torch.bfloat16
+    N, K = 768, 192
+    assert _tile_rows(M, N, K) == 224
+    A, B = _mk((M, K), bf, 0.5), _mk((N, K), bf, 0.2)
+    bias = torch.randn(N, device="cuda")
+    R = _mk((M, N), bf)
+    acc = A.double() @ B.double().t()
+    tol = TOL[bf]
+    C = H.gemm(A, B, M, N, K)
+    assert report("g224 none", C, acc, tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)
+    assert report("g224 bias", C, acc + bias.double(), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=256)
+    ref = acc + bias.double(); ref[:, :256] *= 0.125
+    assert report("g224 qscale", C, ref, tol) <= tol
+    aux = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    pre = acc + bias.double()
+    assert report("g224 gelu.aux", aux, pre, tol) <= tol
+    assert report("g224 gelu.act", C, pre * torch.sigmoid(1.702 * pre), tol) <= tol
+    C2 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias)                 # forward-only: no pre-activation
+    assert torch.equal(C2, C)
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R)
+    assert report("g224 resid", C, acc + bias.double() + R.double(), tol) <= tol
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_GELU_BWD, resid=R)
+    x = R.double(); s = torch.sigmoid(1.702 * x)
+    assert report("g224 gelu_bwd", C, acc * (s * (1 + 1.702 * x * (1 - s))), tol) <= tol
+    # rows past M are never written: a guard band behind the output stays untouched
+    big = torch.full((M + 300, N), 7.0, dtype=bf, device="cuda")
+    H.gemm(A, B, M, N, K, out=big)
+    assert bool((big[M:] == 7.0).all())
+
+
+def test_gemm224_nn_and_f32_slabs():
+    """the dX orientation (N side k-strided: transpose reads gather the permuted columns) on 224-row tiles, and fp32 output
+    through the direct path (two 16-byte stores per lane)"""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(5)
+    bf = torch.bfloat16
+    M, N, K = 18848, 768, 256
+    assert _tile_rows(M, N, K, b_kstrided=True) == 224
+    A, W = _mk((M, K), bf, 0.5), _mk((K, N), bf, 0.2)
+    C = H.gemm(A, W, M, N, K, b_kstrided=True)
+    ref = A.double() @ W.double()
+    assert report("g224 nn", C, ref, TOL[bf]) <= TOL[bf]
+    Cf = H.gemm(A, W, M, N, K, b_kstrided=True, out_dtype=torch.float32)
+    assert report("g224 nn f32", Cf, ref, 2e-5) <= 2e-5
+    B = _mk((N, K), bf, 0.2)
+    Cf = H.gemm(A, B, M, N, K, out_dtype=torch.float32)
+    assert report("g224 nt f32", Cf, A.double() @ B.double().t(), 2e-5) <= 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(18848, 1024, 192), (18848, 3072, 128), (16384, 1280, 256), (40000, 768, 128)])
+def test_gemm256_persistent_tile_loop(M, N, K):
+    """More tiles than CUs in the forward orientation: one workgroup per CU walks several tiles, the next tile's first half-tiles
+    are prefetched under the current tile's stores (gemm256_persist_kernel).  Every epilogue it serves, both tile heights, a ragged
+    last tile, and bit-equality with the one-tile-per-workgroup kernel (same arithmetic, different schedule)."""
+    import os
+    import subprocess
+    import sys
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(M + N)
+    bf = torch.bfloat16
+    A, B = _mk((M, K), bf, 0.5), _mk((N, K), bf, 0.2)
+    bias = torch.randn(N, device="cuda")
+    acc = A.double() @ B.double().t()
+    tol = TOL[bf]
+    C0 = H.gemm(A, B, M, N, K)
+    assert report("persist none", C0, acc, tol) <= tol
+    C1 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)
+    assert report("persist bias", C1, acc + bias.double(), tol) <= tol
+    C2 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=256)
+    ref = acc + bias.double(); ref[:, :256] *= 0.125
+    assert report("persist qscale", C2, ref, tol) <= tol
+    aux = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
+    C3 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    pre = acc + bias.double()
+    assert report("persist gelu.aux", aux, pre, tol) <= tol
+    assert report("persist gelu.act", C3, pre * torch.sigmoid(1.702 * pre), tol) <= tol
+    C4 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias)
+    assert torch.equal(C4, C3)
+    for _ in range(5):                                   # repeated launches: the prefetch / store overlap has no race
+        assert torch.equal(H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias), C1)
+    # the same problems through the one-tile-per-workgroup kernel in a fresh process (the switch is read once per process)
+    torch.save({"A": A.cpu(), "B": B.cpu(), "bias": bias.cpu(), "C1": C1.cpu(), "C3": C3.cpu()}, "/tmp/xp_persist_case.pt")
+    code = ("import torch, sys; sys.path.insert(0, '.');\n"
+            "from xpretrain_amd import hip_ops as H, _lib as L\n"
+            "d = torch.load('/tmp/xp_persist_case.pt'); A, B, bias = d['A'].cuda(), d['B'].cuda(), d['bias'].cuda()\n"
+            "M, K = A.shape; N = B.shape[0]\n"
+            "C1 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)\n"
+            "C3 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias)\n"
+            "assert torch.equal(C1.cpu(), d['C1']) and torch.equal(C3.cpu(), d['C3'])\nprint('same')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, XPRETRAIN_GEMM256_PERSIST="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "same" in out.stdout, out.stderr[-1500:]

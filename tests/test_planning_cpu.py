@@ -44,13 +44,28 @@ def test_auto_split_is_always_accepted():
 def test_fused_colsum_availability():
     lib = L.lib()
     big = dict(a_ks=False, b_ks=True, out=L.XP_BF16)
-    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_GELU_BWD, **big))) == 2 * 74
-    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, **big))) == 2 * 74
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_GELU_BWD, **big))) == 2 * 85      # 85 tiles of 224 rows
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, **big))) == 2 * 85
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(256, 2048, 512, epi=L.EPI_GELU_BWD, **big))) == 0          # text tower: 128 family
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_BIAS, **big))) == 0            # other epilogue
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, a_ks=False, b_ks=True, out=L.XP_F32))) == 0
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, split=2, **big))) == 0
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, dtype=L.XP_F32, **big))) == 0
+
+
+def test_tile_height_planning():
+    """xp_gemm_tile_rows: 224-row tiles where 256-row tiles would leave an eighth of the last round of CUs idle (18848 and
+    50208 token rows of the BASELINE shapes), 256 for weight gradients and exact multiples, 128 = the 128x128 family."""
+    lib = L.lib()
+    act = dict(a_ks=False, b_ks=False, out=L.XP_BF16)
+    for N in (768, 2304, 3072):
+        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, **act))) == 224
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, 768, 3072, a_ks=False, b_ks=True, out=L.XP_BF16))) == 224
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(50208, 768, 768, **act))) == 224
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(3072, 768, 18848, split=7))) == 256        # dW1: 36 tiles x 7 slabs
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(16384, 1024, 512, **act))) == 256
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(256, 2048, 512, **act))) == 128            # text tower
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, 768, 768, dtype=L.XP_F32, a_ks=False, b_ks=False))) == 128
 
 
 def test_partial_row_counts_and_workspaces():

@@ -89,6 +89,7 @@ SIGNATURES = {
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
     "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
     "xp_gemm_colsum_rows": (i64, [C.POINTER(XpGemmDesc)]),
+    "xp_gemm_tile_rows": (i32, [C.POINTER(XpGemmDesc)]),
     "xp_colsum_partial_rows": (i64, [i64, i64]),
     "xp_colsum_partials": (i32, [vp, i64, i64, i64, i32, vp, sz, vp]),
     "xp_reduce_rows_batch_workspace_bytes": (sz, [C.POINTER(XpReduceSeg), i32]),

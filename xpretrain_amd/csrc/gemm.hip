@@ -613,7 +613,16 @@ extern "C" int64_t xp_gemm_colsum_rows(const XpGemmDesc* d) {
   if (!d || d->split_k > 1 || d->in_dtype != XP_BF16 || d->out_dtype != XP_BF16) return 0;
   if (d->epilogue != XP_EPI_NONE && d->epilogue != XP_EPI_GELU_BWD) return 0;
   if (!xp_gemm_fast_epi_ok(d) || !xp_gemm256_wanted(d, 1) || cdiv(d->K, 64) < 2) return 0;
-  return 2 * cdiv(d->M, 256);
+  return xp_gemm256_colsum_rows(d);          // one partial row per wave row block of the tile height the launcher will pick
+}
+
+extern "C" int32_t xp_gemm_tile_rows(const XpGemmDesc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  const int64_t k_per = cdiv(cdiv(d->K, split), 64) * 64;
+  if (xp_gemm256_wanted(d, split) && cdiv(d->K - (int64_t)(split - 1) * k_per, 64) >= 2 && (split == 1 || cdiv(d->K, k_per) == split))
+    return 32 * (4 + xp_gemm256_mt1(d, split));
+  return BM;
 }
 
 // split s0 rounded to one xp_gemm accepts (whole k-steps per slab, no empty slab)

@@ -27,7 +27,7 @@ struct KParams {
   int xcd_remap;             // 1: consecutive tile ids -> same XCD (default); 0: hardware round-robin (A/B switch)
   int wide;                  // 1: N, ldc, ldr, ldaux all multiples of 8 -> 8 columns per lane, 16-byte bf16 stores
   int fast_epi;              // 1: wide, identity cmap, C / resid / aux each < 4 GiB -> branch-free buffer-addressed epilogue
-  float* colsum;             // optional [2 * tiles_m][N] column sums of the finished outputs per 128-row wave block (256 family)
+  float* colsum;             // optional [2 * tiles_m][N] column sums of the finished outputs per wave row block (256 family)
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
 
@@ -258,4 +258,6 @@ __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int gr
 bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st);
 bool xp_gemm256_legal(const XpGemmDesc* d);
 bool xp_gemm256_wanted(const XpGemmDesc* d, int split);
+int xp_gemm256_mt1(const XpGemmDesc* d, int split);
+int64_t xp_gemm256_colsum_rows(const XpGemmDesc* d);
 bool xp_gemm_fast_epi_ok(const XpGemmDesc* d);
