@@ -237,7 +237,10 @@ def main():
     model.to(dev).train()
     D.broadcast_parameters(model)
     loss_fn = NCELearnableTempLoss()
-    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True)
+    import xpretrain_amd.functional as XF
+    # buckets aligned to the encoder layers: the native layer backward writes its gradients straight into bucket storage
+    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True, layout_groups=XF.layer_grad_groups(model),
+                                  wire_dtype={"fp32": None, "bf16": torch.bfloat16}[os.environ.get("XPRETRAIN_GRAD_WIRE", "fp32")])
     use_graph = a.graph == 1
     # pretrain_vip_base_16.json:68-80: adamw, betas (0.9, 0.98), lr 5e-6, wd 0.05, lr_mul 1, cosine decay with 1 % warmup,
     # grad_norm 5.0; grouping = optimization/utils.py:124-154

@@ -339,6 +339,9 @@ int xp_probe_mfma_f32(const float* a, const float* b, float* c, void* stream);
 /* packed-fp32 self-check (csrc/probe.hip): err[(variant*64 + lane)*2 + half] += mismatches between one v_pk_*_f32 form and
  * the same arithmetic in unpacked VALU instructions; 15 variants */
 int xp_probe_pk_f32(void* err /*15*64*2 u32, zeroed by the caller*/, int32_t iters, int32_t blocks, uint32_t seed, void* stream);
+/* memory-bound copy of nbytes (multiple of 16) repeated iters times by `blocks` 256-thread workgroups: a one-GPU stand-in for a
+ * collective's channel kernels beside the backward pass (hvd.DistributedOptimizer's all-reduce, run_pretrain.py:224-227) */
+int xp_probe_stream_copy(void* dst, const void* src, int64_t nbytes, int32_t blocks, int32_t iters, void* stream);
 int xp_probe_tr16(const void* in /*4096 u16*/, const int32_t* lane_byte_off /*64*/, void* out /*64*4 u16*/, void* stream);
 
 #ifdef __cplusplus

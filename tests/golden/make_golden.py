@@ -21,7 +21,7 @@ Fixtures (all fp32, CPU, torch.manual_seed'ed):
                      and logit scales (incl. both clamp limits 0 and ln 200).
   retrieval.pt       src/utils/metrics.py (cal_cossim, np_softmax, compute_metrics, compute_metrics_multi) in the simple
                      and DSL settings of validate(), incl. exact score ties; ImageNorm arithmetic on uint8 frames.
-  full_cfg2.pt, full_cfg3.pt, full_cfg4.pt
+  full_cfg2.pt, full_cfg3.pt, full_cfg4.pt, full_cfg2_b8.pt (configs[1] at the bench batch of 8: features, loss, gradients)
                      BASELINE configs[1], [3], [4] at FULL model size (ViT-B/16; 12x224^2 / 8x448^2 / 32x224^2, 32 text
                      tokens) and batch 2 through the reference VidCLIP.forward + NCELearnableTempLoss + backward, weights
                      rebuilt from seeds (tests/gpu_util.py::seeded_model): features, loss, sampled rows of every hidden
@@ -101,7 +101,7 @@ def tiny_e2e(ref):
     print("tiny_e2e: loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
 
 
-def full_size(ref, name, frames, res, B=2, txt_len=32, patch=16, temporal_size=12):
+def full_size(ref, name, frames, res, B=2, txt_len=32, patch=16, temporal_size=12, hidden=True):
     """One full-size case; what is kept is small (see the module docstring).  Uses this repo's model class only to BUILD
     the seeded weights -- the numbers stored come from the reference."""
     from tests.gpu_util import seeded_model, sample_rows
@@ -145,8 +145,8 @@ def full_size(ref, name, frames, res, B=2, txt_len=32, patch=16, temporal_size=1
             grads[n + "#rows"] = (pick, g2[pick].clone())
     fx = dict(patch=patch, frames=frames, res=res, B=B, txt_len=txt_len, temporal_size=temporal_size, rows=rows,
               vis_features=out["vis_features"].detach(), text_features=out["text_features"].detach(), loss=loss.detach(),
-              vision_hidden=[h[:, rows].detach().half() for h in vo.hidden_states],
-              text_hidden=[h.detach().half() for h in to.hidden_states],
+              vision_hidden=[h[:, rows].detach().half() for h in vo.hidden_states] if hidden else None,
+              text_hidden=[h.detach().half() for h in to.hidden_states] if hidden else None,
               vision_pooled=vo.pooler_output.detach(), text_pooled=to.pooler_output.detach(), grads=grads, ref_bf16=ref_bf16)
     torch.save(fx, os.path.join(HERE, name))
     print(name, "reference bf16 autocast vs fp32:", ref_bf16)
@@ -340,7 +340,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] in ("optim", "retrieval"):
         {"optim": optim, "retrieval": retrieval}[sys.argv[1]](ref)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "full":        # minutes of CPU time each; not part of the default regeneration
+    if len(sys.argv) > 1 and sys.argv[1] == "full_b8":     # the bench batch (8 pairs = 256 text rows): features, loss, gradients
+        full_size(ref, "full_cfg2_b8.pt", 12, 224, B=8, hidden=False)
+        sys.exit(0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":        # minutes of CPU time each; not part of the default regeneration
         for nm, fr, rs in (("full_cfg2.pt", 12, 224), ("full_cfg3.pt", 8, 448), ("full_cfg4.pt", 32, 224)):
             if len(sys.argv) < 3 or sys.argv[2] in nm:
                 full_size(ref, nm, fr, rs)

@@ -172,3 +172,64 @@ def test_bench_starts_its_own_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["world_size"] == 2 and d["n_ranks_seen"] == 2 and d["n_gpus"] == 2, d
+
+
+def _layout_worker(rank, world, port, q):
+    """GradBucketReducer(layout_groups=...): groups are contiguous inside one bucket in the given order, published as gradient
+    sinks; a producer that writes its gradients straight into the sink (as the native layer backward does on the GPU) gets the
+    same averaged gradients as the pack-copy path, with .grad being the bucket views from the start."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from xpretrain_amd import distributed as D
+    import xpretrain_amd.functional as XF
+    D.init_from_env("gloo")
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3, 11, 2, 6, 4)]
+    groups = [[ps[3], ps[1], ps[4]], [ps[6], ps[0]]]          # orders unrelated to the registration order
+    ok = True
+    for wire in (None, torch.bfloat16):
+        red = D.GradBucketReducer(ps, bucket_mb=64 / (1 << 20), average=True, layout_groups=groups, wire_dtype=wire)   # 16 elements
+        for g in groups:
+            key = XF.grad_sink_key(g)
+            sink = XF.GRAD_SINKS[key]
+            ok = ok and sink.numel() == sum(p.numel() for p in g)
+            b = red._bucket_of[id(g[0])]
+            ok = ok and all(red._bucket_of[id(p)] is b for p in g)
+            # the producer: writes the group's flat gradient into the sink, hands autograd views of it
+            off = 0
+            for p in g:
+                sink[off:off + p.numel()] = (rank + 1) * torch.arange(p.numel(), dtype=torch.float32) + p.numel()
+                p.grad = sink[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                red._on_grad(p)
+            views = {id(q): v for q, v in zip(b["params"], b["views"])}
+            ok = ok and all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in g)
+        for p in (ps[2], ps[5]):                               # parameters outside any group: the usual adopted tensors
+            p.grad = torch.full_like(p, float(rank + 1))
+            red._on_grad(p)
+        red.synchronize()
+        mean = (1 + world) / 2
+        for g in groups:
+            for p in g:
+                want = mean * torch.arange(p.numel(), dtype=torch.float32) + p.numel()
+                ok = ok and torch.allclose(p.grad, want, rtol=1e-2 if wire else 1e-6)
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, mean), rtol=1e-2 if wire else 1e-6) for p in (ps[2], ps[5]))
+        red.zero_grad()
+        red.remove()
+        ok = ok and not XF.GRAD_SINKS
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layout_groups_and_gradient_sinks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_layout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

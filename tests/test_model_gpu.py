@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import clipvip_oracle as O
-from tests.gpu_util import TOL, report
+from tests.gpu_util import TOL, loss_gate, report
 
 pytestmark = pytest.mark.gpu
 
@@ -54,8 +54,8 @@ def test_tiny_e2e_against_reference_fixture(golden):
     dt = (out["text_features"].cpu() - fx["text_features"]).abs().max().item()
     loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
     print(f"tiny: dvis {dv:.3e} dtxt {dt:.3e} loss {loss.item():.5f} ref {fx['loss'].item():.5f}")
-    assert dv < 2e-2 and dt < 2e-2
-    assert abs(loss.item() - fx["loss"].item()) < 2e-2 * max(1.0, fx["loss"].item())
+    assert dv < 1.5e-2 and dt < 1.5e-2                       # measured 1.0e-2 / 3.5e-3 (3x-widened weights)
+    assert loss_gate(loss.item(), fx["loss"].item(), 8e-2)  # measured 5.3e-2 on a loss of 25.5 (0.2 %)
     loss.backward()
     bad = []
     for name, p in model.named_parameters():
@@ -99,8 +99,8 @@ def test_cfg1_architecture_against_oracle():
     dv = (out["vis_features"].cpu() - ref_vis).abs().max().item()
     dt = (out["text_features"].cpu() - ref_txt).abs().max().item()
     print(f"cfg1: loss {loss.item():.6f} oracle fp32 {ref_loss.item():.6f} emulation {emu_loss.item():.6f} dvis {dv:.2e} dtxt {dt:.2e}")
-    assert dv <= TOL["features_abs"] and dt <= TOL["features_abs"]
-    assert abs(loss.item() - ref_loss.item()) <= TOL["loss_ref_abs"]
+    assert dv <= TOL["features_abs_full"] and dt <= TOL["features_abs_full"]
+    assert loss_gate(loss.item(), ref_loss.item(), TOL["loss_ref_abs"])
     # The free-running emulation is reported, not gated: two bf16 realisations of a 12-layer network are as far from each
     # other as from fp32; the tight emulation gates are the teacher-forced per-layer ones of test_fullsize_parity_gpu.py.
     worst = {"grad_ref_2d": 0.0, "grad_ref_1d": 0.0}

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""One-GPU proxy for the gradient all-reduce's cost beside the backward pass: bench.py's training step alone, and
+with a memory-bound copy kernel confined to C workgroups (xp_probe_stream_copy -- a ring collective's channel kernels stream the
+gradient buckets the same way) running on a second stream from the start of backward until the optimizer step.
+Usage: python tools/contention_probe.py [steps]"""
+import ctypes as C
+import math
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from oracle import clipvip_oracle as O  # noqa: E402
+from bench import Args  # noqa: E402
+from xpretrain_amd import distributed as D, _lib as L  # noqa: E402
+from xpretrain_amd.modeling import VidCLIP  # noqa: E402
+from xpretrain_amd.optimization import NCELearnableTempLoss, AdamW, build_e2e_optimizer_w_lr_mul  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+torch.manual_seed(1234)
+dev = torch.device("cuda", 0)
+model = VidCLIP(Args(O.vit_b_config(16, 224))).to(dev).train()
+loss_fn = NCELearnableTempLoss()
+reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True)
+groups = build_e2e_optimizer_w_lr_mul(list(model.named_parameters()), 5e-6, 0.05, lr_mul=1, lr_mul_prefix="")
+opt = AdamW([g for g in groups if g["params"]], lr=5e-6, betas=(0.9, 0.98))
+video, ids, mask = [t.to(dev) for t in O.synthetic_inputs(8, 12, 224, 32, seed=4321)]
+ls = model.clipmodel.logit_scale
+side = torch.cuda.Stream(device=dev)
+nbytes = 598 << 20                                       # the fp32 gradient volume of the model
+src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+dst = torch.empty_like(src)
+
+
+def step(blocks=0, iters=1):
+    with torch.no_grad():
+        ls.clamp_(0, math.log(200.0))
+    out = model(video, ids, mask)
+    loss = loss_fn(out["vis_features"], out["text_features"], ls)
+    if blocks:
+        side.wait_stream(torch.cuda.current_stream())
+        L.check(L.lib().xp_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, iters,
+                                             C.c_void_p(side.cuda_stream)), "xp_probe_stream_copy")
+    loss.backward()
+    if blocks:
+        torch.cuda.current_stream().wait_stream(side)
+    opt.clip_and_step(5.0)
+    reducer.zero_grad()
+
+
+def timed(f, n):
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+base = timed(step, steps)
+print(f"step alone: {base:.3f} ms")
+for blocks in (16, 32, 64):
+    def alone():
+        L.check(L.lib().xp_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, 1,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "copy")
+    t_copy = timed(alone, 5)
+    # 2 x 7/8 x 598 MB is what a ring all-reduce moves per GPU on 8 GPUs: one read + one write pass of the buffer ~ iters = 1
+    t = timed(lambda: step(blocks, 1), steps)
+    print(f"{blocks:3d} copy workgroups: copy alone {t_copy:.3f} ms ({2 * nbytes / t_copy / 1e6:.0f} GB/s read+write); step with the copy "
+          f"beside backward {t:.3f} ms (+{t - base:.3f} ms, {100 * (t - base) / base:.1f} %); serial sum would be {base + t_copy:.3f} ms")

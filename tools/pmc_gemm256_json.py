@@ -21,13 +21,14 @@ def source_stamp(root=ROOT):
 
 
 # grid sizes (threads) of the probe's launches: tiles * 512 threads
-VARIANT = {"gemm256_kernel<false, false>": "NT_fc1_fwd", "gemm256_kernel<false, true>": "NS_dpre_dx", "gemm256_kernel<true, true>": "SS_dw1"}
+VARIANT = {"gemm256_persist_kernel<3>": "NT_fc1_fwd", "gemm256_kernel<false, false": "NT_fc1_fwd", "gemm256_kernel<false, true": "NS_dpre_dx",
+           "gemm256_kernel<true, true": "SS_dw1"}
 
 if __name__ == "__main__":
     tag, d, out = sys.argv[1:4]
     res = {"tag": tag, "source_stamp": source_stamp(), "probe": "tools/gemm256_probe.py (cfg #2 shapes, 4 launches each)",
            "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; SQ_* raw", "kernels": {}}
-    for part in ("sq", "fetch", "write"):
+    for part in ("sq", "fetch", "write", "tcc"):
         f = os.path.join(d, f"{tag}_pmc_{part}_gemm256.csv")
         if not os.path.isfile(f):
             continue

@@ -139,6 +139,7 @@ SIGNATURES = {
     "xp_probe_mfma_bf16": (i32, [vp, vp, vp, vp]),
     "xp_probe_mfma_f32": (i32, [vp, vp, vp, vp]),
     "xp_probe_tr16": (i32, [vp, vp, vp, vp]),
+    "xp_probe_stream_copy": (i32, [vp, vp, i64, i32, i32, vp]),
     "xp_probe_pk_f32": (i32, [vp, i32, i32, C.c_uint32, vp]),
 }
 

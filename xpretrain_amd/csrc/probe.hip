@@ -97,6 +97,20 @@ __global__ __launch_bounds__(256) void probe_pk_kernel(unsigned* err, int iters,
 
 }  // namespace
 
+// A memory-bound copy confined to `blocks` workgroups that loops `iters` times over its buffer: a stand-in for a ring
+// collective's kernel (RCCL runs a few dozen channel workgroups that stream the gradient buckets) on a second stream, to measure on
+// ONE GPU what such a neighbour costs the backward pass (tools/contention_probe.py).
+__global__ __launch_bounds__(256) void probe_stream_copy_kernel(u32x4* dst, const u32x4* src, long n16, int iters) {
+  for (int it = 0; it < iters; ++it)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int xp_probe_stream_copy(void* dst, const void* src, int64_t nbytes, int32_t blocks, int32_t iters, void* stream) {
+  XP_REQUIRE(dst && src && nbytes >= 16 && blocks > 0 && iters > 0, "xp_probe_stream_copy: bad arguments");
+  probe_stream_copy_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((u32x4*)dst, (const u32x4*)src, nbytes / 16, iters);
+  XP_CHECK_LAUNCH("xp_probe_stream_copy");
+  return XP_OK;
+}
+
 extern "C" int xp_probe_pk_f32(void* err, int32_t iters, int32_t blocks, uint32_t seed, void* stream) {
   probe_pk_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((unsigned*)err, iters, seed);
   XP_CHECK_LAUNCH("xp_probe_pk_f32");

@@ -257,11 +257,41 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
     return x3, arena
 
 
+# Gradient sinks (distributed.GradBucketReducer(layout_groups=...)): flat fp32 buffers -- slices of the reducer's all-reduce
+# buckets -- keyed by the storage of a layer's 16 parameters.  The native layer backward writes its parameter gradients straight
+# into the sink instead of a private buffer, so the bucket never needs a pack copy.  Used only while every parameter of the layer
+# has ``.grad is None`` (gradient accumulation: the second micro-step must not overwrite what autograd is about to add to).
+GRAD_SINKS = {}
+
+
+def grad_sink_key(params16):
+    return tuple(p.data_ptr() for p in params16)
+
+
+def layer_grad_groups(model):
+    """For ``GradBucketReducer(layout_groups=...)``: the 16 parameters of every CLIPEncoderLayer of ``model`` in the order of the
+    native layer backward's flat gradient buffer (_LayerPlan.gnames; q / k / v rows of the fused dWqkv and dbqkv in that order)."""
+    groups = []
+    for m in model.modules():
+        if all(hasattr(m, a) for a in ("self_attn", "mlp", "layer_norm1", "layer_norm2")):
+            a, f = m.self_attn, m.mlp
+            groups.append([m.layer_norm1.weight, m.layer_norm1.bias, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight,
+                           a.q_proj.bias, a.k_proj.bias, a.v_proj.bias, a.out_proj.weight, a.out_proj.bias,
+                           m.layer_norm2.weight, m.layer_norm2.bias, f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias])
+    return groups
+
+
 def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, plan):
     dev = x.device
     need = ctx.needs_input_grad
     dx = torch.empty_like(x)
-    flat = torch.empty(plan.gtotal, dtype=torch.float32, device=dev)
+    flat = None
+    if GRAD_SINKS and ctx.sink_key is not None and all(need[1:17]):
+        sink = GRAD_SINKS.get(ctx.sink_key)
+        if sink is not None and sink.numel() == plan.gtotal and sink.device == dev and all(p.grad is None for p in ctx.sink_params):
+            flat = sink
+    if flat is None:
+        flat = torch.empty(plan.gtotal, dtype=torch.float32, device=dev)
     parts = flat.split_with_sizes(plan.gsizes)
     ws = H.workspace(plan.bwd_ws, dev, "layer_bwd")
     a = L.XpLayerBwd()
@@ -321,6 +351,11 @@ class EncoderLayerFn(torch.autograd.Function):
                                           keep_pre=training)
             ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask)
             ctx.plan = plan
+            if GRAD_SINKS:          # (data-parallel runs only) the layer's parameters in the flat gradient order
+                ctx.sink_params = (ln1_w, ln1_b, wq, wk, wv, bq, bk, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2)
+                ctx.sink_key = grad_sink_key(ctx.sink_params)
+            else:
+                ctx.sink_params, ctx.sink_key = (), None
             return x3
         ctx.plan = None
 
