@@ -23,6 +23,8 @@
 //         fragments).  Proxy-token partials are reduced over frames by a small kernel.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -290,6 +292,266 @@ __global__ __launch_bounds__(FTHR, 4) void attn_fwd_kernel(AP p) {
   if (g == 0) {
     float* sp = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok_of(p, pr.n, rq)) * 2;
     sp[0] = m; sp[1] = __logf(l);
+  }
+}
+
+// ============================================================================================ forward, persistent + prefetch
+// Round 3.  The kernel above is launched as 2304 independent workgroups, each of which loads the whole K/V of its problem
+// (51 KiB) and then computes; on the hardware that is lock-step: every CU's workgroups load at the same time (an HBM-bound burst,
+// ~11 B/clk/CU: ~4.7k cycles per 51 KiB) and then all compute while HBM idles -- 49 us + 8 us merge for 115.8 MB of q/k/v/o =
+// 0.26 of HBM peak, SQ counters 37 % of wave cycles parked at waits / barriers (profiles/r02c_pmc_sq_attention.csv).  A first
+// rewrite (one 4-wave workgroup per problem, 4 query tiles per wave sharing every fragment read, DMA staging) kept the lock-step
+// and gained 6 us.  This kernel makes the overlap explicit: ONE persistent 8-wave workgroup per CU walks the problems b,
+// b + gridDim.x, ...; K/V are staged by buffer_load...lds DMA into one of two 52 KiB LDS buffers, and the DMA (and the Q row
+// loads) of the NEXT problem are issued before the current one is computed, one barrier per problem.  Wave w owns the query tiles
+// w and w + 8 (2 / 1 of 13), every K / V^T fragment it reads feeds both.  V^T fragments are read by inline-asm transpose reads
+// (common.h::lds_read_tr16_async): hipcc would drain the DMA queue (vmcnt(0)) in front of every ds_read_tr builtin.
+// Measured (tools/attn_trace.py, profiles/r03i_*): 52 us + merge vs 56: the arithmetic of a problem is ~5k cycles per wave and IS
+// hidden, but a problem still takes 15-17k cycles: issuing the next problem's 18 load instructions stalls for ~2.6k cycles and
+// the output stores wait behind them -- the CU moves its 102 KB per problem (Q, K, V in, O out) at 6.4 B/clk, 2.6 TB/s chip-wide,
+// whatever the row pitch of qkv is (tools/attn_layout_probe.py: 384 B vs 4608 B pitch, same time).  The remaining factor to the
+// ~24 us HBM floor is memory-level parallelism per CU, not arithmetic, LDS, or the layout.
+// Serves PROXY problems that fit one LDS group (R <= 208: 224^2 frames at patch 16, any frame count); everything else
+// (448^2: R = 788, the causal text tower) stays on the kernel above.
+constexpr int F3W = 8, F3THR = F3W * 64, F3T = 2;           // waves, threads, query tiles per wave
+constexpr int F3_BUF = 2 * FG * 128;                         // K + V image of one problem
+constexpr int F3_LDS = 2 * F3_BUF;
+
+// K and V rows [0, R) of one problem -> linear swizzled LDS images by LDS-DMA: one wave instruction = 8 rows x 128 B; the
+// XOR swizzle of tile128_off is applied to the per-lane SOURCE chunk; rows >= R read as zero (out-of-range offset)
+__device__ __forceinline__ void fwd3_stage_kv(char* gK, char* gV, const AP& p, const Prob& pr, int lane, int wave) {
+  typedef __attribute__((address_space(3))) char lds_c;
+  const bf16_t* kbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + (int64_t)p.H * DH + pr.h * DH;
+  const unsigned ld_bytes = (unsigned)(p.ldqkv * 2), voff_v = (unsigned)(p.H * DH * 2);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (unsigned)((int64_t)p.S * p.ldqkv * 2 - ((int64_t)p.H * DH + pr.h * DH) * 2), 0x00020000);
+  constexpr int NPASS = FG / 8;                               // 26 passes of 8 rows per operand
+#pragma unroll
+  for (int j = 0; j < (NPASS + F3W - 1) / F3W; ++j) {
+    const int pass = j * F3W + wave;
+    if (pass < NPASS) {
+      const int row = pass * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz128(row);
+      const unsigned off = row < p.R ? (unsigned)tok_of(p, pr.n, row) * ld_bytes + c * 16 : 0xFFFFFF00u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(gK + pass * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(gV + pass * 1024), 16, off, voff_v, 0, 0);
+    }
+  }
+}
+// the wave's Q rows as B-operand fragments
+__device__ __forceinline__ void fwd3_load_q(bf16x8 (&qf)[F3T][2], const AP& p, const Prob& pr, int wave, int lane) {
+  const bf16_t* qbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
+#pragma unroll
+  for (int i = 0; i < F3T; ++i) {
+    const int rq = (wave + F3W * i) * 16 + (lane & 15);
+    load_row_frag(qf[i], qbase + (int64_t)tok_of(p, pr.n, rq < p.R ? rq : 0) * p.ldqkv, rq < p.R, lane >> 4);
+  }
+}
+// transposed fragments by asm reads: the caller waits lgkmcnt(0) before the first use (tools/check_isa.py verifies)
+__device__ __forceinline__ bf16x8 frag_cols_async(const char* tile, int dt, int c, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int r0 = (2 * c) * 16 + 4 * g + (i >> 2);
+  const char* q = tile + tile128_off(r0, dt * 2 + ((i & 3) >> 1)) + ((i & 1) << 3);
+  i16x4 lo = lds_read_tr16_async<0>(q);
+  i16x4 hi = lds_read_tr16_async<16 * 128>(q);               // row + 16: same swizzle phase
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+  i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ s16x4 frag_cols16_async(const char* tile, int dt, int sub, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int r0 = sub * 16 + 4 * g + (i >> 2);
+  return __builtin_bit_cast(s16x4, lds_read_tr16_async<0>(tile + tile128_off(r0, dt * 2 + ((i & 3) >> 1)) + ((i & 1) << 3)));
+}
+
+// one step over NS (1 or 4) sixteen-key sub-tiles for the wave's NTL (1 or 2) query tiles; TAIL: the step reaches past key R
+// (masking code exists in that instantiation only -- as a run-time condition hipcc if-converts it into 32 compares + 32 selects
+// per tile in EVERY step).  The loop is VALU-issue bound (stamped: ~2.2k cycles per 64-key step of two tiles for 512 cycles of
+// MFMA), so the softmax is written for instruction count: running max kept finite (-1e30: no -inf guards), exp2 of one fma per
+// score (log2 e folded in), two independent partial sums.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float M_INIT = -1e30f;
+template <int NS, int NTL, bool TAIL>
+__device__ __forceinline__ void fwd3_step(FwdState (&st)[F3T], const AP& p, int frame, const char* gK, const char* gV,
+                                          const bf16x8 (&qf)[F3T][2], int t0, int wave, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, kb = t0 * 16;
+  f32x4 s[NTL][NS];
+  {
+    bf16x8 kf[NS][2];
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) kf[t][kk] = frag_rows(gK, t0 + t, kk, lane);
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        s[i][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) s[i][t] = mma16(kf[t][kk], qf[i][kk], s[i][t]);
+      }
+  }
+  // V^T fragments of the step: issued now, consumed after the softmax arithmetic
+  const char* sV = gV + t0 * 16 * 128;               // row shift by a multiple of 16 keeps the swizzle phase
+  bf16x8 vf[NS / 2 > 0 ? NS / 2 : 1][4];
+  s16x4 vt[4];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < NS / 2; ++c)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vf[c][dt] = frag_cols_async(sV, dt, c, lane);
+  if constexpr (NS & 1) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vt[dt] = frag_cols16_async(sV, dt, NS - 1, lane);
+  }
+  bf16x8 pf[NTL][NS / 2 > 0 ? NS / 2 : 1];
+  s16x4 pt[NTL];
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) {
+    if constexpr (TAIL) {                             // the lane's key rows are kb + 16t + 4g + r: valid iff 16t + r < klim
+      const int klim = p.R - kb - 4 * g;
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[i][t][r] = (16 * t + r < klim) ? s[i][t][r] : -INFINITY;
+    }
+    // proxy query rows meet proxy keys: counted in frame 0 only (CLIP_ViP.py:366-375 attends them once over all S keys)
+    if (i == 0 && t0 == 0 && wave == 0 && frame != 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[0][0][r] = (i16 < p.M && 4 * g + r < p.M) ? -INFINITY : s[0][0][r];
+    }
+    float tmax = s[i][0][0];
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[i][t][r]);
+    tmax = group_max(tmax);
+    const float mnew = fmaxf(st[i].m, tmax);          // >= M_INIT: finite
+    const float alpha = __builtin_amdgcn_exp2f((st[i].m - mnew) * LOG2E);
+    const float nmc = -mnew * LOG2E;
+    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[i][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][t][r], LOG2E, nmc));
+      ps0 += s[i][t][0] + s[i][t][1];
+      ps1 += s[i][t][2] + s[i][t][3];
+    }
+    st[i].l = st[i].l * alpha + (ps0 + ps1);
+    st[i].m = mnew;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st[i].o[dt] *= alpha;
+#pragma unroll
+    for (int c = 0; c < NS / 2; ++c) pf[i][c] = pack_p(s[i][2 * c], s[i][2 * c + 1]);
+    if constexpr (NS & 1) pt[i] = pack_p4(s[i][NS - 1]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < NS / 2; ++c)
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) st[i].o[dt] = mma16(vf[c][dt], pf[i][c], st[i].o[dt]);
+  if constexpr (NS & 1) {
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) st[i].o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[dt], pt[i], st[i].o[dt], 0, 0, 0);
+  }
+}
+
+// all key steps of one problem for the wave's NTL tiles, then normalise and store
+template <int NTL>
+__device__ __forceinline__ void fwd3_problem(const AP& p, const Prob& pr, int prob, const char* gK, const char* gV,
+                                             const bf16x8 (&qf)[F3T][2], int nsub, int wave, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  FwdState st[F3T];
+#pragma unroll
+  for (int i = 0; i < F3T; ++i) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st[i].o[dt] = f32x4{0, 0, 0, 0};
+    st[i].m = M_INIT; st[i].l = 0.f;
+  }
+  int t0 = 0;
+  for (; t0 + 4 <= nsub && (t0 + 4) * 16 <= p.R; t0 += 4) fwd3_step<4, NTL, false>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+  // the rest: 1..4 sub-tiles, the last of which may reach past R.  A 2- or 3-sub-tile rest runs the 4-wide step with its
+  // surplus keys masked (rows < FG of the images are always written -- zeros past R -- and t0 <= 8 here)
+  if (t0 < nsub) {
+    if (nsub - t0 == 1) {
+      if (nsub * 16 > p.R) fwd3_step<1, NTL, true>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+      else                 fwd3_step<1, NTL, false>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+    } else {
+      fwd3_step<4, NTL, true>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) {
+    const int rq = (wave + F3W * i) * 16 + i16;
+    const float m = st[i].m;
+    const float l = group_sum(st[i].l);
+    if (rq >= p.R) continue;
+    if (rq < p.M) {
+      float* part = p.ws0 + ((int64_t)prob * p.M + rq) * PART;
+      if (g == 0) { part[0] = m; part[1] = l; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(part + 2 + dt * 16 + 4 * g, st[i].o[dt]);
+      continue;
+    }
+    const int tok = tok_of(p, pr.n, rq);
+    const float inv = 1.0f / l;
+    bf16_t* orow = p.out + ((int64_t)pr.b * p.S + tok) * p.ldo + pr.h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + 4 * g, st[i].o[dt] * inv);
+    if (g == 0) {
+      float* sp = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok) * 2;
+      sp[0] = m; sp[1] = __logf(l);
+    }
+  }
+}
+
+__global__ __launch_bounds__(F3THR, 2) void attn_fwd3_kernel(AP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsub = (p.R + 15) / 16;                       // sixteen-row tiles of the problem (<= 13)
+  const int nt = (nsub - wave + F3W - 1) / F3W;           // this wave's query tiles: wave, wave + 8
+  int prob = blockIdx.x;
+  if (prob >= p.nprob) return;
+  int cur = 0;
+  bf16x8 qf[F3T][2], qn[F3T][2];
+  {
+    const Prob pr(p, prob);
+    fwd3_stage_kv(smem, smem + FG * 128, p, pr, lane, wave);
+    fwd3_load_q(qf, p, pr, wave, lane);
+  }
+  unsigned long long* tr = (p.ws2 && (int)blockIdx.x == (int)gridDim.x / 2 && (wave == 0 || wave == 7) && lane == 0)
+                               ? reinterpret_cast<unsigned long long*>(p.ws2) + (wave ? 64 : 0) : nullptr;   // xp_debug_set_attn_trace
+  int it = 0;
+  for (;;) {
+    if (tr && it < 8) tr[it * 4 + 0] = __builtin_amdgcn_s_memtime();
+    __syncthreads();                                      // (vmcnt(0) + barrier) this problem's K/V have landed everywhere, and
+    if (tr && it < 8) tr[it * 4 + 1] = __builtin_amdgcn_s_memtime();
+    const Prob pr(p, prob);                               // every wave is done with the other buffer
+    const int next = prob + (int)gridDim.x;
+    char* gK = smem + cur * F3_BUF;
+    if (next < p.nprob) {
+      const Prob pn(p, next);
+      char* nK = smem + (cur ^ 1) * F3_BUF;
+      fwd3_stage_kv(nK, nK + FG * 128, p, pn, lane, wave);
+      fwd3_load_q(qn, p, pn, wave, lane);
+    }
+    if (tr && it < 8) tr[it * 4 + 2] = __builtin_amdgcn_s_memtime();
+    if (nt == 2)      fwd3_problem<2>(p, pr, prob, gK, gK + FG * 128, qf, nsub, wave, lane);
+    else if (nt == 1) fwd3_problem<1>(p, pr, prob, gK, gK + FG * 128, qf, nsub, wave, lane);
+    if (tr && it < 8) tr[it * 4 + 3] = __builtin_amdgcn_s_memtime();
+    ++it;
+    if (next >= p.nprob) break;
+#pragma unroll
+    for (int i = 0; i < F3T; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) qf[i][kk] = qn[i][kk];
+    prob = next; cur ^= 1;
   }
 }
 
@@ -688,7 +950,19 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   p.ws2 = (float*)g_attn_trace;
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)(B * H * N);
-  attn_fwd_kernel<<<(unsigned)(cdiv(p.nprob, 8) * 8 * p.nq), FTHR, 0, st>>>(p);
+  static const int fwd3 = getenv("XPRETRAIN_ATTN_FWD3") ? atoi(getenv("XPRETRAIN_ATTN_FWD3")) : 1;     // A/B switch
+  if (fwd3 && mode == XP_ATTN_PROXY && p.R <= FG && !pad_mask) {
+    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
+                                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static std::once_flag configured;
+    std::call_once(configured, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS);
+    });
+    const int fgrid = fwd3 > 1 ? fwd3 : ncu;              // (XPRETRAIN_ATTN_FWD3=<n>: grid size, for experiments)
+    attn_fwd3_kernel<<<(unsigned)(p.nprob < fgrid ? p.nprob : fgrid), F3THR, F3_LDS, st>>>(p);
+  } else {
+    attn_fwd_kernel<<<(unsigned)(cdiv(p.nprob, 8) * 8 * p.nq), FTHR, 0, st>>>(p);
+  }
   XP_CHECK_LAUNCH("xp_attn_fwd");
   if (mode == XP_ATTN_PROXY) {
     attn_fwd_merge_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
