@@ -77,6 +77,12 @@ typedef struct XpGemmDesc {
    * Only where xp_gemm_colsum_rows() > 0 (large bf16 problems, EPI_NONE / EPI_GELU_BWD); finish with
    * xp_reduce_rows_batch. */
   float* colsum_partials;
+  /* 0: library default (256-row tiles where the 256-wide family runs); 224: prefer 224-row tiles where they fill the last round
+   * of CUs better.  On MI355X the GEMMs run against the power limit: at 18848 rows 224-row tiles finish a forward-only pass 3.8 %
+   * sooner but cost 0.7 % more time per training step (more N-side operand traffic per FLOP), so latency-first callers (inference
+   * forward: retrieval, tasks/run_video_retrieval.py:123-203) ask for 224 and the training step keeps 256. */
+  int32_t tile_rows_hint;
+  int32_t reserved0;
 } XpGemmDesc;
 
 int xp_gemm(const XpGemmDesc* desc, void* stream);
@@ -130,9 +136,11 @@ int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float
                      float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, void* stream);
 size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
 /* Deferred form: dx is final, the parameter gradients stay as xp_layernorm_bwd_partial_rows(rows) partial rows in
- * the workspace -- [dgamma(cols) | dbeta(cols)] (pitch 2*cols), or with with_dx_colsum != 0
+ * the workspace -- [dgamma(cols) | dbeta(cols)] (pitch 2*cols); with with_dx_colsum == 1
  * [dgamma | dbeta | colsum(dx)] (pitch 3*cols; the column sums of the dx just written = the bias gradient of the
- * Linear in front of this residual add) -- for xp_reduce_rows_batch. */
+ * Linear in front of this residual add); with with_dx_colsum == 2 (needs dres) [dgamma | dbeta | colsum(dx) | colsum(dres)]
+ * (pitch 4*cols; in CLIPEncoderLayer's second LayerNorm, CLIP_ViP.py:455-458, dres is the layer's incoming gradient, whose
+ * column sums are fc2's bias gradient) -- for xp_reduce_rows_batch. */
 int64_t xp_layernorm_bwd_partial_rows(int64_t rows);
 int xp_layernorm_bwd_partials(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
                               const float* mean, const float* rstd, const void* dres, int64_t lddres,
@@ -169,6 +177,15 @@ int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dou
                 const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
                 int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the bias gradients of q_proj / k_proj / v_proj on the way (autograd computes them as dqkv.sum(0),
+ * CLIP_ViP.py:341-343): every backward workgroup also leaves the column sums of the dqkv rows it stores (as stored, i.e. rounded)
+ * as one partial row: dqkv_colsum_partials[r * 3*H*64 + c], r < xp_attn_bwd_colsum_rows(...) -- finish with xp_reduce_rows_batch.
+ * Saves the separate pass over dqkv.  xp_attn_bwd_colsum_rows() == 0 (fp32 mode): not available, pass NULL. */
+int64_t xp_attn_bwd_colsum_rows(int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype);
+int xp_attn_bwd2(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
+                 const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
+                 int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
+                 void* workspace, size_t workspace_bytes, float* dqkv_colsum_partials, void* stream);
 
 /* --------------------------------------------------------------------------------- Embeddings / glue
  * CLIPVisionViPEmbeddings.forward (modeling/CLIP_ViP.py:168-197).

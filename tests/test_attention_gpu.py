@@ -94,3 +94,30 @@ def test_attention_rejects_bad_shapes():
     qkv = torch.zeros(10 * 3, 3 * 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError, match="M\\+N\\*L"):
         Hh.attn_fwd(qkv, 3, 10, 1, size=(4, 2, 2))
+
+
+@pytest.mark.parametrize("geom", [(4, 12, 196), (4, 2, 49), (1, 3, 5), None])
+def test_backward_emits_the_qkv_bias_column_sums(geom):
+    """xp_attn_bwd2: the bias gradients of q/k/v_proj (column sums of dqkv as stored) come out of the backward kernels -- frame rows
+    from the dQ / dKV workgroups, proxy rows from the proxy reduce -- and equal a separate pass over dqkv; the causal text pattern
+    (ragged padding) too."""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(11)
+    B, Hh = 2, 3
+    if geom is None:
+        S, size = 32, None
+        pad = torch.ones(B, S, dtype=torch.int64, device="cuda"); pad[0, 20:] = 0
+    else:
+        M, N, Lp = geom
+        S, size, pad = M + N * Lp, geom, None
+    qkv = (torch.randn(B * S, 3 * Hh * 64, device="cuda") * 0.7).to(torch.bfloat16)
+    out, stats = H.attn_fwd(qkv, B, S, Hh, size=size, pad_mask=pad)
+    dout = torch.randn_like(out)
+    ref = H.attn_bwd(qkv, out, dout, stats, B, S, Hh, size=size, pad_mask=pad, q_scale=0.125)
+    d = H.DeferredReduce(qkv.device)
+    dqkv, cs = H.attn_bwd(qkv, out, dout, stats, B, S, Hh, size=size, pad_mask=pad, q_scale=0.125, colsum_defer=d)
+    assert len(d.segs) == 1                      # the fused path: one partial-row segment, no extra pass
+    d.flush()
+    assert torch.equal(dqkv, ref)
+    want = dqkv.double().sum(0)
+    assert report(f"attn bwd fused colsum {geom}", cs, want, 1e-5, scale_floor=1e-3) <= 1e-5

@@ -210,7 +210,7 @@ def test_gemm_fused_colsum(epi):
     defer = H.DeferredReduce(dY.device)
     kw = dict(epilogue=L.EPI_GELU_BWD, resid=pre) if epi == "gelu_bwd" else {}
     out, cs = H.gemm(dY, W, M, N, K, b_kstrided=True, colsum_defer=defer, **kw)
-    assert len(defer.segs) == 1 and defer.segs[0].nrows == 2 * ((M + 223) // 224)      # the fused path was taken (224-row tiles)
+    assert len(defer.segs) == 1 and defer.segs[0].nrows == 2 * ((M + 255) // 256)      # the fused path was taken (256-row tiles)
     defer.flush()
     ref = dY.double() @ W.double()
     if epi == "gelu_bwd":
@@ -225,18 +225,21 @@ def test_gemm_fused_colsum(epi):
 
 
 # ---------------------------------------------------------------------------------------------- 224-row tiles, direct epilogue
-def _tile_rows(M, N, K, b_kstrided=False, split_k=1, out_f32=False):
+def _tile_rows(M, N, K, b_kstrided=False, split_k=1, out_f32=False, hint=224):
     import ctypes as C
     from xpretrain_amd import _lib as L
     d = L.XpGemmDesc()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr, d.ldaux = M, N, K, K, (N if b_kstrided else K), N, N, N
     d.b_kstrided, d.in_dtype, d.out_dtype, d.split_k = int(b_kstrided), L.XP_BF16, (L.XP_F32 if out_f32 else L.XP_BF16), split_k
+    d.tile_rows_hint = hint
     return int(L.lib().xp_gemm_tile_rows(C.byref(d)))
 
 
 def test_tile_height_is_chosen_per_shape():
-    """BASELINE cfg #2 token count: 85 tiles of 224 rows fill 1 / 3 / 4 rounds of the CUs (74 of 256 rows: 0.87 of them);
+    """BASELINE cfg #2 token count: 85 tiles of 224 rows fill 1 / 3 / 4 rounds of the CUs (74 of 256 rows: 0.87 of them) -- used when
+    the caller asks for them (tile_rows_hint = 224: latency-first forward passes), the default stays 256 (energy per training step);
     a multiple of 256 keeps 256-row tiles; small problems stay in the 128x128 family."""
+    assert _tile_rows(18848, 768, 768, hint=0) == 256 and _tile_rows(18848, 3072, 768, b_kstrided=True, hint=0) == 256
     assert _tile_rows(18848, 768, 768) == 224 and _tile_rows(18848, 2304, 768) == 224 and _tile_rows(18848, 3072, 768) == 224
     assert _tile_rows(18848, 768, 3072, b_kstrided=True) == 224
     assert _tile_rows(50208, 768, 768) == 224              # configs[3]/[4] token count
@@ -259,28 +262,28 @@ def test_gemm224_nt_all_epilogues(M):
     R = _mk((M, N), bf)
     acc = A.double() @ B.double().t()
     tol = TOL[bf]
-    C = H.gemm(A, B, M, N, K)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=224)
     assert report("g224 none", C, acc, tol) <= tol
-    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=224, epilogue=L.EPI_BIAS, bias=bias)
     assert report("g224 bias", C, acc + bias.double(), tol) <= tol
-    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=256)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=224, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=256)
     ref = acc + bias.double(); ref[:, :256] *= 0.125
     assert report("g224 qscale", C, ref, tol) <= tol
     aux = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
-    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=224, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux)
     pre = acc + bias.double()
     assert report("g224 gelu.aux", aux, pre, tol) <= tol
     assert report("g224 gelu.act", C, pre * torch.sigmoid(1.702 * pre), tol) <= tol
-    C2 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias)                 # forward-only: no pre-activation
+    C2 = H.gemm(A, B, M, N, K, tile_rows_hint=224, epilogue=L.EPI_BIAS_GELU, bias=bias)                 # forward-only: no pre-activation
     assert torch.equal(C2, C)
-    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=224, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R)
     assert report("g224 resid", C, acc + bias.double() + R.double(), tol) <= tol
-    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_GELU_BWD, resid=R)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=224, epilogue=L.EPI_GELU_BWD, resid=R)
     x = R.double(); s = torch.sigmoid(1.702 * x)
     assert report("g224 gelu_bwd", C, acc * (s * (1 + 1.702 * x * (1 - s))), tol) <= tol
     # rows past M are never written: a guard band behind the output stays untouched
     big = torch.full((M + 300, N), 7.0, dtype=bf, device="cuda")
-    H.gemm(A, B, M, N, K, out=big)
+    H.gemm(A, B, M, N, K, out=big, tile_rows_hint=224)
     assert bool((big[M:] == 7.0).all())
 
 
@@ -293,13 +296,13 @@ def test_gemm224_nn_and_f32_slabs():
     M, N, K = 18848, 768, 256
     assert _tile_rows(M, N, K, b_kstrided=True) == 224
     A, W = _mk((M, K), bf, 0.5), _mk((K, N), bf, 0.2)
-    C = H.gemm(A, W, M, N, K, b_kstrided=True)
+    C = H.gemm(A, W, M, N, K, b_kstrided=True, tile_rows_hint=224)
     ref = A.double() @ W.double()
     assert report("g224 nn", C, ref, TOL[bf]) <= TOL[bf]
-    Cf = H.gemm(A, W, M, N, K, b_kstrided=True, out_dtype=torch.float32)
+    Cf = H.gemm(A, W, M, N, K, b_kstrided=True, out_dtype=torch.float32, tile_rows_hint=224)
     assert report("g224 nn f32", Cf, ref, 2e-5) <= 2e-5
     B = _mk((N, K), bf, 0.2)
-    Cf = H.gemm(A, B, M, N, K, out_dtype=torch.float32)
+    Cf = H.gemm(A, B, M, N, K, out_dtype=torch.float32, tile_rows_hint=224)
     assert report("g224 nt f32", Cf, A.double() @ B.double().t(), 2e-5) <= 2e-5
 
 
@@ -321,6 +324,7 @@ def test_gemm256_persistent_tile_loop(M, N, K):
     tol = TOL[bf]
     C0 = H.gemm(A, B, M, N, K)
     assert report("persist none", C0, acc, tol) <= tol
+    assert torch.equal(H.gemm(A, B, M, N, K, tile_rows_hint=224), C0)       # 224-row tiles: same k order, bit-identical
     C1 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)
     assert report("persist bias", C1, acc + bias.double(), tol) <= tol
     C2 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=256)

@@ -77,9 +77,16 @@ def test_reduce_rows_batch_and_deferred_producers():
         dx1, dg1, db1 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, defer=d, name="ln_a")
         dres = torch.randn(rows, cols, device="cuda").to(dtype)
         dx2, dg2, db2, dxs = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, dres=dres, defer=d, dx_colsum=True, name="ln_b")
+        # 4-vector partials: additionally the column sums of the residual gradient the kernel reads (fc2's bias gradient)
+        dx3, dg3, db3, dxs3, drs3 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, dres=dres, defer=d, dx_colsum=True,
+                                                    dres_colsum=True, name="ln_c")
         with pytest.raises(RuntimeError, match="two producers"):      # slots are named: a second producer of a name cannot alias
             H.colsum_deferred(X, rows, cols, d)
         d.flush()
+        assert torch.equal(dx3, dx2)
+        assert report(f"ln dres colsum {dtype}", drs3, dres.double().sum(0), 1e-5) <= 1e-5
+        assert report(f"ln dx colsum (4-vector partials) {dtype}", dxs3, dxs, 2e-6) <= 2e-6
+        assert report(f"ln dgamma (4-vector partials) {dtype}", dg3, dg2, 2e-6) <= 2e-6
         assert report(f"ln dx colsum {dtype}", dxs, dx2.double().sum(0), 3e-3 if dtype == torch.bfloat16 else 1e-5) <= 3e-3
         assert report(f"ln dgamma (3-vector partials) {dtype}", dg2, dg1, 2e-6) <= 2e-6
         dx0, dg0, db0 = H.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols)

@@ -39,6 +39,7 @@ class XpGemmDesc(C.Structure):
         ("aux", vp), ("ldaux", i64),
         ("tab1", vp), ("tab2", vp), ("tab_L", i64),
         ("colsum_partials", vp),
+        ("tile_rows_hint", i32), ("reserved0", i32),
     ]
 
 
@@ -108,6 +109,8 @@ SIGNATURES = {
     "xp_attn_workspace_bytes": (sz, [i32, i64, i64, i64, i64, i64]),
     "xp_attn_fwd": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
     "xp_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "xp_attn_bwd2": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp, vp]),
+    "xp_attn_bwd_colsum_rows": (i64, [i32, i64, i64, i64, i64, i64, i64, i32]),
     "xp_im2col": (i32, [vp, vp, i64, i64, i64, i64, i32, vp]),
     "xp_im2col_u8": (i32, [vp, C.POINTER(f32), C.POINTER(f32), vp, i64, i64, i64, i64, i32, vp]),
     "xp_vip_proxy_rows": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]),

@@ -41,6 +41,7 @@ struct AP {
   int nq, nprob;                        // forward: query blocks per problem, problems
   float q_scale;
   float* ws0; float* ws1; float* ws2;   // fwd: partials | bwd: delta, dq partials, dkv partials
+  float* cs; int cs_main;               // bwd, optional: column-sum partial rows of dqkv [cs_main + B*M][3*H*64] (see xp_attn_bwd2)
 };
 
 struct Prob {
@@ -610,6 +611,33 @@ __device__ __forceinline__ bool wg_problem(const AP& p, int& prob, int& blk) {
   return prob < p.nprob;
 }
 
+// Column sums over the workgroup's FINISHED rows (one row per lane column i16, d = 16*dt + 4*g + r) of values already rounded to
+// the storage type: butterfly over the 16 row lanes, one LDS slot per wave, thread d sums the 7 waves in fixed order and writes
+// dst[d].  Every thread of the workgroup must call it (two barriers); `red` may alias the staging tiles (no longer read).
+__device__ __forceinline__ void wg_colsum64(f32x4 (&v)[4], float* red, float* dst, int wave, int lane, int tid) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[dt][r] += __shfl_xor(v[dt][r], o, 64);
+  __syncthreads();
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(red + wave * DH + dt * 16 + 4 * (lane >> 4), v[dt]);
+  }
+  __syncthreads();
+  if (tid < DH) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) a += red[w * DH + tid];
+    dst[tid] = a;
+  }
+}
+__device__ __forceinline__ f32x4 round_bf16(f32x4 x) {
+  return f32x4{(float)(bf16_t)x[0], (float)(bf16_t)x[1], (float)(bf16_t)x[2], (float)(bf16_t)x[3]};
+}
+
 // ---- dK, dV: the workgroup owns 112 key rows; loops over the problem's query rows (Q, dO, m, log l, delta staged) ----
 struct DkvState { f32x4 dk[4], dv[4]; };
 
@@ -749,18 +777,30 @@ __global__ __launch_bounds__(FTHR, 4) void attn_bwd_dkv_kernel(AP p) {
       else              dkv_step<2>(st, p, pr, gQ, gDO, gM, gLg, gDl, kf, vf, t0, qb, rk, kvalid, kpad, wkey0, lane);
     }
   }
-  if (!kvalid) return;
-  if (p.mode == XP_ATTN_PROXY && rk < p.M) {
+  const bool partial_row = kvalid && p.mode == XP_ATTN_PROXY && rk < p.M;      // proxy keys: per-frame partials, reduced later
+  const bool final_row = kvalid && !partial_row;
+  if (partial_row) {
     float* part = p.ws2 + ((int64_t)prob * p.M + rk) * (2 * DH);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, st.dk[dt]); store4(part + DH + dt * 16 + 4 * g, st.dv[dt]); }
-    return;
   }
-  bf16_t* base = p.dqkv + ktok * p.ldqkv + pr.h * DH;
+  if (final_row) {
+    bf16_t* base = p.dqkv + ktok * p.ldqkv + pr.h * DH;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, st.dk[dt]);
-    store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, st.dv[dt]);
+    for (int dt = 0; dt < 4; ++dt) {
+      store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, st.dk[dt]);
+      store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, st.dv[dt]);
+    }
+  }
+  if (p.cs) {          // bias gradients of k_proj / v_proj: column sums of the rows just stored (as stored: rounded)
+    float* row = p.cs + ((int64_t)(pr.b * p.N + pr.n) * p.nq + blk) * (3 * p.H * DH) + pr.h * DH;
+    f32x4 v[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v[dt] = final_row ? round_bf16(st.dk[dt]) : f32x4{0, 0, 0, 0};
+    wg_colsum64(v, reinterpret_cast<float*>(smem), row + p.H * DH, wave, lane, tid);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v[dt] = final_row ? round_bf16(st.dv[dt]) : f32x4{0, 0, 0, 0};
+    wg_colsum64(v, reinterpret_cast<float*>(smem), row + 2 * p.H * DH, wave, lane, tid);
   }
 }
 
@@ -868,16 +908,25 @@ __global__ __launch_bounds__(FTHR, 4) void attn_bwd_dq_kernel(AP p) {
       else         dq_step<4>(dq, p, pr, gK, gV, gPad, qf, dof, mq, lgq, dlq, t0, kb, rq, qvalid, wrow0, lane);
     }
   }
-  if (!qvalid) return;
-  if (p.mode == XP_ATTN_PROXY && rq < p.M) {
+  const bool partial_row = qvalid && p.mode == XP_ATTN_PROXY && rq < p.M;
+  const bool final_row = qvalid && !partial_row;
+  if (partial_row) {
     float* part = p.ws1 + ((int64_t)prob * p.M + rq) * DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4(part + dt * 16 + 4 * g, dq[dt]);
-    return;
   }
-  bf16_t* base = p.dqkv + qtok * p.ldqkv + pr.h * DH;
+  if (final_row) {
+    bf16_t* base = p.dqkv + qtok * p.ldqkv + pr.h * DH;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) store4(base + dt * 16 + 4 * g, dq[dt] * p.q_scale);
+    for (int dt = 0; dt < 4; ++dt) store4(base + dt * 16 + 4 * g, dq[dt] * p.q_scale);
+  }
+  if (p.cs) {          // bias gradient of q_proj
+    float* row = p.cs + ((int64_t)(pr.b * p.N + pr.n) * p.nq + blk) * (3 * p.H * DH) + pr.h * DH;
+    f32x4 v[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v[dt] = final_row ? round_bf16(dq[dt] * p.q_scale) : f32x4{0, 0, 0, 0};
+    wg_colsum64(v, reinterpret_cast<float*>(smem), row, wave, lane, tid);
+  }
 }
 
 // proxy tokens: sum the per-frame partials.  grid = B*H*M, 64 lanes = d
@@ -892,9 +941,14 @@ __global__ void attn_bwd_proxy_reduce_kernel(AP p) {
     v += p.ws2[pi * 2 * DH + DH + d];
   }
   bf16_t* base = p.dqkv + ((int64_t)b * p.S + mrow) * p.ldqkv + h * DH + d;
-  base[0] = (bf16_t)(q * p.q_scale);
-  base[(int64_t)p.H * DH] = (bf16_t)k;
-  base[(int64_t)2 * p.H * DH] = (bf16_t)v;
+  const bf16_t qb = (bf16_t)(q * p.q_scale), kb = (bf16_t)k, vb = (bf16_t)v;
+  base[0] = qb;
+  base[(int64_t)p.H * DH] = kb;
+  base[(int64_t)2 * p.H * DH] = vb;
+  if (p.cs) {          // the proxy rows' contribution to the bias column sums: one partial row per (sample, proxy token)
+    float* row = p.cs + ((int64_t)p.cs_main + b * p.M + mrow) * (3 * p.H * DH) + h * DH + d;
+    row[0] = (float)qb; row[(int64_t)p.H * DH] = (float)kb; row[(int64_t)2 * p.H * DH] = (float)vb;
+  }
 }
 
 int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L,
@@ -971,11 +1025,28 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   return XP_OK;
 }
 
+extern "C" int64_t xp_attn_bwd_colsum_rows(int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype) {
+  if (dtype != XP_BF16) return 0;                    // the fp32 kernels do not produce them: callers run xp_colsum_partials
+  if (mode == XP_ATTN_CAUSAL) { M = 0; N = 1; L = S; }
+  else if (mode != XP_ATTN_PROXY) return 0;
+  return B * N * cdiv(M + L, FQ) + B * M;
+}
+
 extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
                            const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
                            int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
                            void* workspace, size_t workspace_bytes, void* stream) {
+  return xp_attn_bwd2(qkv, ldqkv, out, dout, ldo, stats, pad_mask, dqkv, q_scale, mode, B, H, S, M, N, L, dtype, workspace,
+                      workspace_bytes, nullptr, stream);
+}
+
+extern "C" int xp_attn_bwd2(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
+                            const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
+                            int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,
+                            void* workspace, size_t workspace_bytes, float* dqkv_colsum_partials, void* stream) {
   XP_REQUIRE(qkv && out && dout && stats && dqkv, "xp_attn_bwd: null pointer");
+  XP_REQUIRE(!dqkv_colsum_partials || xp_attn_bwd_colsum_rows(mode, B, H, S, M, N, L, dtype) > 0,
+             "xp_attn_bwd2: fused column sums are not available for this problem (xp_attn_bwd_colsum_rows() == 0)");
   if (mode == XP_ATTN_CAUSAL) { M = 0; N = 1; L = S; }
   int rc = check_common("xp_attn_bwd", mode, B, H, S, M, N, L, ldqkv, ldo, dtype);
   if (rc) return rc;
@@ -992,6 +1063,7 @@ extern "C" int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, cons
   p.ws0 = (float*)workspace; p.ws1 = p.ws0 + B * H * S; p.ws2 = p.ws1 + P * M * DH;
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)P;
+  p.cs = dqkv_colsum_partials; p.cs_main = (int)(B * N * p.nq);
   const unsigned grid = (unsigned)(cdiv(p.nprob, 8) * 8 * p.nq);
   attn_bwd_dq_kernel<<<grid, FTHR, 0, st>>>(p);          // also computes delta = rowsum(dO * O) into ws0
   XP_CHECK_LAUNCH("xp_attn_bwd(dq)");

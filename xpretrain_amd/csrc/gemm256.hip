@@ -6,9 +6,10 @@
 // the bytes staged per FLOP (64 KiB per 2048 MFMA cycles) and doubles the MFMAs per LDS fragment read.
 //
 //   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); wave tile (64 + 16*MT1) x 64 = (4 + MT1) x 4 accumulators
-//   tile       TM x 256 with TM = 2 * (64 + 16 * MT1): 256 (MT1 = 4), 224 (MT1 = 3), 192 (MT1 = 2).  The height is chosen per
-//              problem (xp_gemm256_mt1): 18848 rows are 73.6 tiles of 256 -- 74 x {3, 9, 12} = 222 / 666 / 888 workgroups fill
-//              0.87 of 1 / 3 / 4 rounds of the 256 CUs -- but 85 tiles of 224: 255 / 765 / 1020 = 0.996 of 1 / 3 / 4 rounds.
+//   tile       TM x 256 with TM = 2 * (64 + 16 * MT1): 256 (MT1 = 4), 224 (MT1 = 3), 192 (MT1 = 2).  18848 rows are 73.6 tiles of
+//              256 -- 74 x {3, 9, 12} = 222 / 666 / 888 workgroups fill 0.87 of 1 / 3 / 4 rounds of the 256 CUs -- but 85 tiles of
+//              224: 255 / 765 / 1020 = 0.996 of 1 / 3 / 4 rounds.  Which one is used is a policy (xp_gemm256_mt1 below): 224 for
+//              latency-first forward passes, 256 where energy per step counts.
 //   k-tile     64 bf16 of k = four 16 KiB HALF-TILES.  Half 0 of the M-side tile holds rows {wm*WR + r} (r < 64), half 1 rows
 //              {wm*WR + 64 + r} (r < 16*MT1; the remaining LDS rows are zero-filled by the DMA's bounds check and never
 //              multiplied) of both wave rows (WR = 64 + 16*MT1); half h of the N-side tile the 32 columns {wn*64 + h*32 + ..}
@@ -533,13 +534,21 @@ bool epi_supported(const XpGemmDesc* d) {
 
 }  // namespace
 
-// Tile height: MT1 = sub-tiles of the second M half (4: 256 rows, 3: 224, 2: 192 -- 192 is not instantiated).  Cost model of a
-// launch = rounds of the 256 CUs x (MFMA work of a tile + its height-independent part: the N-side operand, prologue and
-// epilogue), in units of one 16-row sub-tile per wave.  XPRETRAIN_GEMM256_MT1=3|4 forces a height (A/B experiments).
+// Tile height: MT1 = sub-tiles of the second M half (4: 256 rows, 3: 224, 2: 192 -- 192 is not instantiated).
+//   default (desc->tile_rows_hint == 0): 256 rows.  Measured inside the training step at cfg #2 (three interleaved rounds on one
+//     box, profiles/r03n_bench_ab_tile_height_in_step.txt): 224-row tiles for forward + dX GEMMs 17.14 ms/step, forward only 17.08,
+//     dX only 17.09, 256 everywhere 17.02 -- the step is energy-bound (tools/clock_probe.hip) and the 224-row tile moves 14 % more
+//     N-side operand bytes per FLOP, although in isolation it is 1-7 % faster per GEMM (idle CUs of the last round lend power);
+//   hint 224: the height that minimises rounds x (sub-tiles + height-independent part) -- a forward-only pass is 3.8 % faster with
+//     it (4.59 vs 4.77 ms): the inference forward asks for it (csrc/layer.hip, pre == NULL).
+//   XPRETRAIN_GEMM256_MT1 / _MT1_NS = 3|4 force a height for all / for the dX orientation (A/B experiments).
 int xp_gemm256_mt1(const XpGemmDesc* d, int split) {
   if (d->a_kstrided) return 4;                       // weight-gradient GEMMs: M = n_out is a multiple of 256
   static const int forced = getenv("XPRETRAIN_GEMM256_MT1") ? atoi(getenv("XPRETRAIN_GEMM256_MT1")) : 0;
+  static const int forced_ns = getenv("XPRETRAIN_GEMM256_MT1_NS") ? atoi(getenv("XPRETRAIN_GEMM256_MT1_NS")) : 0;   // dX orientation only
+  if (d->b_kstrided && (forced_ns == 3 || forced_ns == 4)) return forced_ns;
   if (forced == 3 || forced == 4) return forced;
+  if (d->tile_rows_hint != 224) return 4;
   int best = 4;
   double best_cost = 0;
   for (int mt1 = 4; mt1 >= 3; --mt1) {

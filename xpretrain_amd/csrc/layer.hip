@@ -80,26 +80,27 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
              a->rstd1 && a->mean2 && a->rstd2 && a->stats, "xp_encoder_layer_fwd: null pointer");
   const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
   const int dt = d.dtype;
+  const int hint = a->pre ? 0 : 224;       // forward-only pass (no pre-activation kept): latency first -> 224-row GEMM tiles
   // h1 = LN1(x)
   if ((rc = xp_layernorm_fwd(a->x, D, a->ln1_w, a->ln1_b, a->h1, D, a->mean1, a->rstd1, rows, D, d.ln_eps, dt, st))) return rc;
   // qkv = (h1 Wqkv^T + b), q columns scaled by dh^-0.5 (:341)
   XpGemmDesc g = gemm_desc(a->h1, a->Wqkv, a->qkv, rows, 3 * D, D, dt);
-  g.epilogue = XP_EPI_BIAS_QSCALE; g.bias = a->bqkv; g.scale = d.q_scale; g.scale_cols = D;
+  g.epilogue = XP_EPI_BIAS_QSCALE; g.bias = a->bqkv; g.scale = d.q_scale; g.scale_cols = D; g.tile_rows_hint = hint;
   if ((rc = xp_gemm(&g, st))) return rc;
   if ((rc = xp_attn_fwd(a->qkv, 3 * D, a->attn_o, D, a->stats, a->pad_mask, d.attn_mode, d.B, d.heads, d.S, d.M, d.N, d.L, dt,
                         a->workspace, a->workspace_bytes, st))) return rc;
   // x2 = x + attn_o Wo^T + bo
   g = gemm_desc(a->attn_o, a->Wo, a->x2, rows, D, D, dt);
-  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->bo; g.resid = a->x;
+  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->bo; g.resid = a->x; g.tile_rows_hint = hint;
   if ((rc = xp_gemm(&g, st))) return rc;
   if ((rc = xp_layernorm_fwd(a->x2, D, a->ln2_w, a->ln2_b, a->h2, D, a->mean2, a->rstd2, rows, D, d.ln_eps, dt, st))) return rc;
   // pre = h2 W1^T + b1 ; act = quick_gelu(pre)
   g = gemm_desc(a->h2, a->W1, a->act, rows, Dff, D, dt);
-  g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre;
+  g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre; g.tile_rows_hint = hint;
   if ((rc = xp_gemm(&g, st))) return rc;
   // x3 = x2 + act W2^T + b2
   g = gemm_desc(a->act, a->W2, a->x3, rows, D, Dff, dt);
-  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->b2; g.resid = a->x2;
+  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->b2; g.resid = a->x2; g.tile_rows_hint = hint;
   return xp_gemm(&g, st);
 }
 
@@ -109,6 +110,7 @@ namespace {
 struct BwdPlan {
   size_t esz, dpre, dh, dqkv, slabs, cs_pre, cs_dx3, ln2, cs_qkv, ln1, red, attn, total;
   int64_t cs_pre_rows, cs_dx3_rows, cs_qkv_rows, ln_rows;
+  bool cs_qkv_fused;
 };
 BwdPlan plan_bwd(const XpLayerDims& d) {
   BwdPlan p;
@@ -128,8 +130,12 @@ BwdPlan plan_bwd(const XpLayerDims& d) {
   p.cs_pre_rows = xp_gemm_colsum_rows(&g);
   const int64_t pre_rows = p.cs_pre_rows > 0 ? p.cs_pre_rows : xp_colsum_partial_rows(rows, Dff);
   p.cs_pre = align256(pre_rows * Dff * sizeof(float));
-  p.cs_dx3_rows = xp_colsum_partial_rows(rows, D); p.cs_dx3 = align256(p.cs_dx3_rows * D * sizeof(float));
-  p.cs_qkv_rows = xp_colsum_partial_rows(rows, 3 * D); p.cs_qkv = align256(p.cs_qkv_rows * 3 * D * sizeof(float));
+  p.cs_dx3_rows = 0; p.cs_dx3 = 0;           // fc2's bias gradient = column sums of dx3: taken by the second LayerNorm's backward
+  // the q/k/v bias gradients: out of the attention backward kernels where they offer it, else a column-sum pass over dqkv
+  p.cs_qkv_rows = xp_attn_bwd_colsum_rows(d.attn_mode, d.B, d.heads, d.S, d.M, d.N, d.L, d.dtype);
+  p.cs_qkv_fused = p.cs_qkv_rows > 0;
+  if (!p.cs_qkv_fused) p.cs_qkv_rows = xp_colsum_partial_rows(rows, 3 * D);
+  p.cs_qkv = align256(p.cs_qkv_rows * 3 * D * sizeof(float));
   p.ln_rows = xp_layernorm_bwd_partial_rows(rows);
   p.ln2 = p.ln1 = align256(xp_layernorm_bwd_workspace_bytes(rows, D));
   p.red = align256((size_t)XP_REDUCE_MAX_SEGS * 32 * (size_t)(3 * D > Dff ? 3 * D : Dff) * sizeof(float) + 16);
@@ -180,33 +186,30 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
     }
   }
   if (a->dw2 && (rc = wgrad(a->dx3, a->act, a->dw2, rows, D, Dff, dt, slabs, p.slabs, st))) return rc;
-  if (a->db2) {
-    if ((rc = xp_colsum_partials(a->dx3, rows, D, D, dt, cs_dx3, p.cs_dx3, st))) return rc;
-    df.add(cs_dx3, a->db2, D, (int)p.cs_dx3_rows, (int)D);
-  }
   g = gemm_desc(dpre, a->W1, dh2, rows, D, Dff, dt);                          // dh2 = dpre . W1
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
   if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, st))) return rc;
-  // dx2 = dx3 + LN2'(dh2); partial rows [dgamma | dbeta | colsum(dx2)] -- the last one is out_proj's bias gradient
-  if ((rc = xp_layernorm_bwd_partials(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 1, rows, D, dt,
+  // dx2 = dx3 + LN2'(dh2); partial rows [dgamma | dbeta | colsum(dx2) | colsum(dx3)] -- out_proj's and fc2's bias gradients
+  if ((rc = xp_layernorm_bwd_partials(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 2, rows, D, dt,
                                       ln2_part, p.ln2, st))) return rc;
-  df.add(ln2_part, a->dln2_w, 3 * D, (int)p.ln_rows, (int)D);
-  df.add(ln2_part + D, a->dln2_b, 3 * D, (int)p.ln_rows, (int)D);
-  df.add(ln2_part + 2 * D, a->dbo, 3 * D, (int)p.ln_rows, (int)D);
+  df.add(ln2_part, a->dln2_w, 4 * D, (int)p.ln_rows, (int)D);
+  df.add(ln2_part + D, a->dln2_b, 4 * D, (int)p.ln_rows, (int)D);
+  df.add(ln2_part + 2 * D, a->dbo, 4 * D, (int)p.ln_rows, (int)D);
+  df.add(ln2_part + 3 * D, a->db2, 4 * D, (int)p.ln_rows, (int)D);
   // ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
   g = gemm_desc(dx2, a->Wo, dattn, rows, D, D, dt);                           // dattn = dx2 . Wo
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
   if (a->dwo && (rc = wgrad(dx2, a->attn_o, a->dwo, rows, D, D, dt, slabs, p.slabs, st))) return rc;
-  if ((rc = xp_attn_bwd(a->qkv, 3 * D, a->attn_o, dattn, D, a->stats, a->pad_mask, dqkv, d.q_scale, d.attn_mode, d.B, d.heads,
-                        d.S, d.M, d.N, d.L, dt, attn_ws, p.attn, st))) return rc;
+  if ((rc = xp_attn_bwd2(a->qkv, 3 * D, a->attn_o, dattn, D, a->stats, a->pad_mask, dqkv, d.q_scale, d.attn_mode, d.B, d.heads,
+                         d.S, d.M, d.N, d.L, dt, attn_ws, p.attn, (a->dbqkv && p.cs_qkv_fused) ? cs_qkv : nullptr, st))) return rc;
   g = gemm_desc(dqkv, a->Wqkv, dh1, rows, D, 3 * D, dt);                      // dh1 = dqkv . Wqkv
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
   if (a->dwqkv && (rc = wgrad(dqkv, a->h1, a->dwqkv, rows, 3 * D, D, dt, slabs, p.slabs, st))) return rc;
   if (a->dbqkv) {
-    if ((rc = xp_colsum_partials(dqkv, rows, 3 * D, 3 * D, dt, cs_qkv, p.cs_qkv, st))) return rc;
+    if (!p.cs_qkv_fused && (rc = xp_colsum_partials(dqkv, rows, 3 * D, 3 * D, dt, cs_qkv, p.cs_qkv, st))) return rc;
     df.add(cs_qkv, a->dbqkv, 3 * D, (int)p.cs_qkv_rows, (int)(3 * D));
   }
   if ((rc = xp_layernorm_bwd_partials(dh1, D, a->x, D, a->ln1_w, a->mean1, a->rstd1, dx2, D, a->dx, D, 0, rows, D, dt,

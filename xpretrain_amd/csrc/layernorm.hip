@@ -67,22 +67,28 @@ template <> struct Raw4<bf16_t> { typedef bf16x4 type; };
 __device__ __forceinline__ f32x4 cvt4(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 cvt4(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-// DXS: also accumulate the column sums of the dx this kernel writes (the bias gradient of the Linear whose output feeds
-// the residual stream here); the partial rows are then [dgamma | dbeta | dxsum].
-template <typename T, int NJ, bool DXS>
+// DXS = 1: also accumulate the column sums of the dx this kernel writes (the bias gradient of the Linear whose output feeds
+// the residual stream here); the partial rows are then [dgamma | dbeta | dxsum].  DXS = 2: additionally the column sums of the
+// residual gradient `dres` it reads anyway (in an encoder layer's second LayerNorm that is dx3: the bias gradient of fc2, which
+// otherwise costs a separate pass over dx3): [dgamma | dbeta | dxsum | dressum].
+template <typename T, int NJ, int DXS>
 __global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* dres, int64_t lddres,
                                                      T* dx, int64_t lddx, float* __restrict__ part,
                                                      int64_t rows, int cols) {
-  constexpr int NV = DXS ? 3 : 2;
+  constexpr int NV = 2 + DXS;
   __shared__ float red[WAVES][NV][NJ * 256];
   typedef typename Raw4<T>::type raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 gm[NJ], dg[NJ], db[NJ], dxs[DXS ? NJ : 1];
-  if constexpr (DXS) {
+  f32x4 gm[NJ], dg[NJ], db[NJ], dxs[DXS ? NJ : 1], drs[DXS == 2 ? NJ : 1];
+  if constexpr (DXS != 0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) dxs[j] = f32x4{0, 0, 0, 0};
+  }
+  if constexpr (DXS == 2) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) drs[j] = f32x4{0, 0, 0, 0};
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -140,7 +146,8 @@ __global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __res
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs[u] * (gy[j][e] - c1 - xh[j][e] * c2) + rv[e];
           store4(dx + rws[u] * lddx + c, o);
-          if constexpr (DXS) dxs[j] += o;
+          if constexpr (DXS != 0) dxs[j] += o;
+          if constexpr (DXS == 2) drs[j] += rv;
         }
       }
     }
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __res
     const int c = j * 256 + lane * 4;
     if (c < cols) {
       store4(&red[wave][0][c], dg[j]); store4(&red[wave][1][c], db[j]);
-      if constexpr (DXS) store4(&red[wave][2][c], dxs[j]);
+      if constexpr (DXS != 0) store4(&red[wave][2][c], dxs[j]);
+      if constexpr (DXS == 2) store4(&red[wave][3][c], drs[j]);
     }
   }
   __syncthreads();
@@ -230,18 +238,19 @@ extern "C" int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
 }
 
 extern "C" size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
-  return (size_t)(bwd_blocks(rows) + 32) * 3 * cols * sizeof(float);
+  return (size_t)(bwd_blocks(rows) + 32) * 4 * cols * sizeof(float);
 }
 
 namespace {
 int ln_bwd_launch(const char* name, const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, int64_t lddres, void* dx, int64_t lddx, int64_t rows, int64_t cols,
-                  int32_t dtype, bool dxs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                  int32_t dtype, int dxs, void* workspace, size_t workspace_bytes, hipStream_t st) {
   XP_REQUIRE(dy && x && gamma && mean && rstd && dx, "%s: null pointer", name);
   XP_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXJ * 256, "%s: cols=%lld unsupported", name, (long long)cols);
   XP_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "%s: ld must be a multiple of 4", name);
   XP_REQUIRE(workspace && workspace_bytes >= xp_layernorm_bwd_workspace_bytes(rows, cols), "%s: workspace too small", name);
   XP_REQUIRE(dtype == XP_BF16 || dtype == XP_F32, "%s: bad dtype %d", name, dtype);
+  XP_REQUIRE(dxs >= 0 && dxs <= 2 && (dxs != 2 || dres), "%s: with_dx_colsum must be 0, 1 or 2 (2 needs dres)", name);
   const int blocks = bwd_blocks(rows);
   float* part = (float*)workspace;
   const int nj = (int)cdiv(cols, 256);
@@ -250,8 +259,8 @@ int ln_bwd_launch(const char* name, const void* dy, int64_t lddy, const void* x,
                                                   lddres, (T*)dx, lddx, part, rows, (int)cols)
 #define XP_LN_BWD_NJ(T, D)                                                                                            \
   do { if (nj == 1) XP_LN_BWD(T, 1, D); else if (nj == 2) XP_LN_BWD(T, 2, D); else if (nj == 3) XP_LN_BWD(T, 3, D); else XP_LN_BWD(T, 4, D); } while (0)
-  if (dtype == XP_BF16) { if (dxs) XP_LN_BWD_NJ(bf16_t, true); else XP_LN_BWD_NJ(bf16_t, false); }
-  else                  { if (dxs) XP_LN_BWD_NJ(float, true);  else XP_LN_BWD_NJ(float, false); }
+  if (dtype == XP_BF16) { if (dxs == 2) XP_LN_BWD_NJ(bf16_t, 2); else if (dxs) XP_LN_BWD_NJ(bf16_t, 1); else XP_LN_BWD_NJ(bf16_t, 0); }
+  else                  { if (dxs == 2) XP_LN_BWD_NJ(float, 2);  else if (dxs) XP_LN_BWD_NJ(float, 1);  else XP_LN_BWD_NJ(float, 0); }
 #undef XP_LN_BWD_NJ
 #undef XP_LN_BWD
   XP_CHECK_LAUNCH(name);
@@ -266,7 +275,7 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                                 void* workspace, size_t workspace_bytes, void* stream) {
   XP_REQUIRE(dgamma && dbeta, "xp_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  int rc = ln_bwd_launch("xp_layernorm_bwd", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype, false,
+  int rc = ln_bwd_launch("xp_layernorm_bwd", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype, 0,
                          workspace, workspace_bytes, st);
   if (rc) return rc;
   // two-level deterministic reduce of the per-block partial rows: blocks -> <=32 -> 1; dgamma/dbeta may be two
@@ -291,5 +300,5 @@ extern "C" int xp_layernorm_bwd_partials(const void* dy, int64_t lddy, const voi
                                          void* dx, int64_t lddx, int32_t with_dx_colsum, int64_t rows, int64_t cols,
                                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
   return ln_bwd_launch("xp_layernorm_bwd_partials", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype,
-                       with_dx_colsum != 0, workspace, workspace_bytes, (hipStream_t)stream);
+                       with_dx_colsum, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -359,14 +359,15 @@ class EncoderLayerFn(torch.autograd.Function):
             return x3
         ctx.plan = None
 
+        hint = 0 if training else 224       # forward-only pass: latency-first GEMM tiles (as csrc/layer.hip)
         h1, mean1, rstd1 = H.layernorm_fwd(x, ln1_w, ln1_b, rows, D)
-        qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D)
+        qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D, tile_rows_hint=hint)
         attn_o, stats = H.attn_fwd(qkv, B, S, heads, size=size, pad_mask=pad_mask)
-        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x)
+        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x, tile_rows_hint=hint)
         h2, mean2, rstd2 = H.layernorm_fwd(x2, ln2_w, ln2_b, rows, D)
         pre = torch.empty((rows, Dff), dtype=dt, device=x.device) if training else None
-        act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre)
-        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2)
+        act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre, tile_rows_hint=hint)
+        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2, tile_rows_hint=hint)
 
         if training:
             ctx.save_for_backward(x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
@@ -399,24 +400,28 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre), None
         dw2 = _wgrad(dx3, act, rows, D, Dff) if need[15] else None
-        db2 = H.colsum_deferred(dx3, rows, D, defer, name="db2") if need[16] else None
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
         dw1 = _wgrad(dpre, h2, rows, Dff, D) if need[13] else None
-        # out_proj's bias gradient = column sums of dx2: accumulated by the LayerNorm backward that writes dx2
-        dx2, dln2_w, dln2_b, dbo = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
-                                                   dx_colsum=True, name="ln2")
+        # out_proj's bias gradient = column sums of dx2, fc2's = column sums of dx3: both accumulated by the LayerNorm backward
+        # that reads dx3 and writes dx2
+        dx2, dln2_w, dln2_b, dbo, db2 = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
+                                                        dx_colsum=True, dres_colsum=True, name="ln2")
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
         dwo = _wgrad(dx2, attn_o, rows, D, D) if need[9] else None
-        dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
+        want_bqkv = need[4] or need[6] or need[8]
+        if want_bqkv:       # the q/k/v bias gradients (column sums of dqkv) come out of the attention backward kernels
+            dqkv, dbqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale,
+                                     colsum_defer=defer, colsum_name="dbqkv")
+        else:
+            dqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale)
         dh1 = H.gemm(dqkv, Wqkv, rows, D, 3 * D, b_kstrided=True)
         if need[3] or need[5] or need[7]:
             dwqkv = _wgrad(dqkv, h1, rows, 3 * D, D)
             dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         else:
             dwq = dwk = dwv = None
-        if need[4] or need[6] or need[8]:
-            dbqkv = H.colsum_deferred(dqkv, rows, 3 * D, defer, name="dbqkv")
+        if want_bqkv:
             dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
         else:
             dbq = dbk = dbv = None
@@ -424,7 +429,7 @@ class EncoderLayerFn(torch.autograd.Function):
         defer.flush()
         keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
         return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),
-                keep(12, dln2_b), dw1, db1, dw2, db2, None, None, None, None, None, None)
+                keep(12, dln2_b), dw1, db1, dw2, keep(16, db2), None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ embeddings

@@ -59,7 +59,8 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
          a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
          scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
-         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None, colsum_name="gemm_colsum"):
+         a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None, colsum_name="gemm_colsum",
+         tile_rows_hint=0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc.
 
     ``colsum_defer`` (a DeferredReduce): also return the column sums of C (a bias gradient), as ``(C, colsum)``; the
@@ -92,6 +93,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     d.tab1 = 0 if tab1 is None else _chk(tab1, "tab1", torch.float32).data_ptr()
     d.tab2 = 0 if tab2 is None else _chk(tab2, "tab2", torch.float32).data_ptr()
     d.tab_L = tab_L
+    d.tile_rows_hint = tile_rows_hint
     if colsum_defer is None:
         L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
         return out
@@ -207,8 +209,9 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, dres=None, dx=None, lddx=None,
-                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None, dx_colsum=False, name="ln"):
-    """Returns (dx, dgamma, dbeta) -- plus colsum(dx) when ``dx_colsum`` (deferred mode only)."""
+                  dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None, dx_colsum=False, dres_colsum=False,
+                  name="ln"):
+    """Returns (dx, dgamma, dbeta) -- plus colsum(dx) when ``dx_colsum``, plus colsum(dres) when ``dres_colsum`` (deferred mode only)."""
     _chk(dy, "dy"); _chk(x, "x", dy.dtype)
     dx = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device) if dx is None else dx
     dgamma = torch.empty(cols, dtype=torch.float32, device=dy.device) if dgamma is None else dgamma
@@ -217,15 +220,21 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, 
     if defer is not None:     # parameter-gradient partial rows stay in their own slot until defer.flush()
         ws = defer.slot(nb, name)
         L.check(L.lib().xp_layernorm_bwd_partials(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
-                                                  _p(dres), cols, _p(dx), lddx or cols, int(dx_colsum), rows, cols,
+                                                  _p(dres), cols, _p(dx), lddx or cols, 2 if dres_colsum else int(dx_colsum), rows, cols,
                                                   _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd_partials")
         nrows = L.lib().xp_layernorm_bwd_partial_rows(rows)
-        pitch = (3 if dx_colsum else 2) * cols
+        if dres_colsum and not (dx_colsum and dres is not None):
+            raise ValueError("layernorm_bwd: dres_colsum needs dx_colsum and dres")
+        pitch = (4 if dres_colsum else 3 if dx_colsum else 2) * cols
         defer.add(ws, 0, dgamma, nrows, cols, pitch, accumulate)
         defer.add(ws, cols, dbeta, nrows, cols, pitch, accumulate)
         if dx_colsum:
             dxs = torch.empty(cols, dtype=torch.float32, device=dy.device)
             defer.add(ws, 2 * cols, dxs, nrows, cols, pitch)
+            if dres_colsum:
+                drs = torch.empty(cols, dtype=torch.float32, device=dy.device)
+                defer.add(ws, 3 * cols, drs, nrows, cols, pitch)
+                return dx, dgamma, dbeta, dxs, drs
             return dx, dgamma, dbeta, dxs
         return dx, dgamma, dbeta
     if dx_colsum:
@@ -427,12 +436,23 @@ def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, *, size=None, pad_mask=N
     return out, stats
 
 
-def attn_bwd(qkv, out, dout, stats, B, S, H, *, size=None, pad_mask=None, q_scale=1.0):
+def attn_bwd(qkv, out, dout, stats, B, S, H, *, size=None, pad_mask=None, q_scale=1.0, colsum_defer=None,
+             colsum_name="dbqkv"):
+    """dqkv; with ``colsum_defer`` (a DeferredReduce) also the column sums of dqkv (the q/k/v bias gradients) as ``(dqkv, colsum)``:
+    out of the backward kernels where the library supports it, otherwise from a separate pass; final after ``flush()``."""
     mode = L.ATTN_PROXY if size is not None else L.ATTN_CAUSAL
     M, N, Lp = size if size is not None else (0, 1, S)
     dqkv = torch.empty_like(qkv)
     ws = _attn_ws(mode, B, H, M, N, Lp, qkv.device)
-    L.check(L.lib().xp_attn_bwd(_p(qkv), 3 * H * 64, _p(out), _p(dout), H * 64, _p(stats), _p(pad_mask), _p(dqkv),
-                                float(q_scale), mode, B, H, S, M, N, Lp, _dt(qkv), _p(ws), ws.numel(), _stream()),
+    nrows = int(L.lib().xp_attn_bwd_colsum_rows(mode, B, H, S, M, N, Lp, _dt(qkv))) if colsum_defer is not None else 0
+    part = colsum_defer.slot(nrows * 3 * H * 64 * 4, colsum_name) if nrows else None
+    L.check(L.lib().xp_attn_bwd2(_p(qkv), 3 * H * 64, _p(out), _p(dout), H * 64, _p(stats), _p(pad_mask), _p(dqkv),
+                                 float(q_scale), mode, B, H, S, M, N, Lp, _dt(qkv), _p(ws), ws.numel(), _p(part), _stream()),
             "xp_attn_bwd")
-    return dqkv
+    if colsum_defer is None:
+        return dqkv
+    if not nrows:
+        return dqkv, colsum_deferred(dqkv, B * S, 3 * H * 64, colsum_defer, name=colsum_name)
+    cs = torch.empty(3 * H * 64, dtype=torch.float32, device=qkv.device)
+    colsum_defer.add(part, 0, cs, nrows, 3 * H * 64, 3 * H * 64)
+    return dqkv, cs
