@@ -82,7 +82,13 @@ typedef struct XpGemmDesc {
    * sooner but cost 0.7 % more time per training step (more N-side operand traffic per FLOP), so latency-first callers (inference
    * forward: retrieval, tasks/run_video_retrieval.py:123-203) ask for 224 and the training step keeps 256. */
   int32_t tile_rows_hint;
-  int32_t reserved0;
+  int32_t side_M;
+  /* optional, EPI_BIAS_RESID: fp32 "side rows" of the residual stream.  Output rows m with m % side_S < side_M (the video tower's
+   * proxy tokens: rows [0, M) of every sample of S tokens, CLIP_ViP.py:187-197) take their residual operand from
+   * resid_side[((m / side_S) * side_M + m % side_S) * N + n] (fp32) instead of resid, and their fp32 result is ALSO written to
+   * out_side (same indexing) next to the rounded C row.  The pooled feature is token 0 of the last layer: keeping the residual
+   * stream of these few rows in fp32 halves the feature error of the bf16 path (tools/residual_precision_experiment.py). */
+  const float* resid_side; float* out_side; int64_t side_S;
 } XpGemmDesc;
 
 int xp_gemm(const XpGemmDesc* desc, void* stream);
@@ -134,6 +140,12 @@ int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, void* workspac
  */
 int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                      float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, void* stream);
+/* The same with fp32 side rows of the residual stream (see XpGemmDesc::resid_side): row r with r % side_S < side_M is READ from
+ * x_side[((r / side_S) * side_stride + r % side_S) * cols] (fp32) instead of x when x_side != NULL, and its fp32 result is ALSO
+ * written to y_side (same indexing) when y_side != NULL (pre_layrnorm, CLIP_ViP.py:881: its output is the residual stream). */
+int xp_layernorm_fwd_side(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                          float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype,
+                          const float* x_side, float* y_side, int64_t side_S, int32_t side_M, int32_t side_stride, void* stream);
 size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
 /* Deferred form: dx is final, the parameter gradients stay as xp_layernorm_bwd_partial_rows(rows) partial rows in
  * the workspace -- [dgamma(cols) | dbeta(cols)] (pitch 2*cols); with with_dx_colsum == 1
@@ -321,6 +333,12 @@ typedef struct XpLayerFwd {
   void* h1; void* qkv; void* attn_o; void* x2; void* h2; void* pre; void* act; void* x3;
   float* mean1; float* rstd1; float* mean2; float* rstd2; float* stats;   /* stats [B,heads,S,2]                    */
   void* workspace; size_t workspace_bytes;                                /* >= xp_encoder_layer_fwd_workspace_bytes */
+  /* optional (bf16): fp32 side rows of the residual stream -- rows r with r % side_S < side_M, stored at side row
+   * (r / side_S) * side_M + r % side_S of a [.., D] fp32 buffer: the M proxy tokens of every video sample (side_S = S, side_M = M),
+   * or the whole stream of the small text tower (side_S = side_M = 1).  side_in = those rows of x in fp32 (read by LayerNorm 1 and as
+   * out_proj's residual operand), side_out = those rows of x3 in fp32 (the intermediate x2 rows live in the workspace).  Both NULL:
+   * plain bf16 stream.  See XpGemmDesc::resid_side. */
+  const float* side_in; float* side_out; int64_t side_S; int32_t side_M; int32_t reserved;
 } XpLayerFwd;
 size_t xp_encoder_layer_fwd_workspace_bytes(const XpLayerDims* dims);
 int xp_encoder_layer_fwd(const XpLayerFwd* args, void* stream);

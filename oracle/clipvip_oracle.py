@@ -49,6 +49,17 @@ class _Rounding:
     gradients are fp32 in the HIP path), which makes the emulation a tight reference for the backward.  Default: off."""
     dtype = None
     grads = False
+    proxy_fp32 = True          # the HIP path keeps the M proxy rows of the video tower's residual stream in fp32 (functional.PROXY_SIDE)
+
+    def resid(self, t: Tensor, size) -> Tensor:
+        """rounding of the RESIDUAL STREAM [B,S,D]: with ``proxy_fp32`` the first M rows of every video-tower sample (``size`` =
+        (M, N, L)) and the whole stream of the text tower (``size`` None) stay exact"""
+        if self.dtype is None or not self.proxy_fp32:
+            return self(t)
+        if size is None:
+            return t
+        M = size[0]
+        return torch.cat([t[:, :M], self(t[:, M:])], dim=1)
 
     def __call__(self, t: Tensor, grad: bool = True) -> Tensor:
         if self.dtype is None:
@@ -92,11 +103,13 @@ class OracleCfg:
 
 
 # ----------------------------------------------------------------------------- primitives
-def layer_norm(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
-    """nn.LayerNorm over the last dim, biased variance, eps 1e-5 (CLIP_ViP.py:404-406)."""
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, resid_size=None) -> Tensor:
+    """nn.LayerNorm over the last dim, biased variance, eps 1e-5 (CLIP_ViP.py:404-406).  ``resid_size``: the output IS the
+    residual stream of the video tower (pre_layrnorm): emulated storage rounding follows ROUND.resid."""
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return ROUND((x - mu) * torch.rsqrt(var + LN_EPS) * w + b)
+    y = (x - mu) * torch.rsqrt(var + LN_EPS) * w + b
+    return ROUND.resid(y, resid_size) if resid_size is not None else ROUND(y)
 
 
 def quick_gelu(x: Tensor) -> Tensor:
@@ -191,10 +204,10 @@ def encoder_layer(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int,
                   size: Optional[Tuple[int, int, int]], pad_mask: Optional[Tensor]) -> Tensor:
     """Pre-LN block, CLIPEncoderLayer.forward else-branch (CLIP_ViP.py:444-460)."""
     h = layer_norm(x, sd[pfx + "layer_norm1.weight"], sd[pfx + "layer_norm1.bias"])
-    x = ROUND(x + attention_block(h, sd, pfx + "self_attn.", heads, size, pad_mask))
+    x = ROUND.resid(x + attention_block(h, sd, pfx + "self_attn.", heads, size, pad_mask), size)
     h = layer_norm(x, sd[pfx + "layer_norm2.weight"], sd[pfx + "layer_norm2.bias"])
     h = linear(ROUND(quick_gelu(linear(h, sd, pfx + "mlp.fc1"))), sd, pfx + "mlp.fc2")   # CLIPMLP :392-396
-    return ROUND(x + h)
+    return ROUND.resid(x + h, size)
 
 
 def encoder(x: Tensor, sd: Dict[str, Tensor], pfx: str, cfg: TowerCfg,
@@ -235,7 +248,7 @@ def vip_embeddings(video: Tensor, sd: Dict[str, Tensor], cfg: OracleCfg):
     cls = sd["vision_model.embeddings.class_embedding"][None, None, :].expand(B, 1, D) + pos[0]
     add = sd["vision_model.embeddings.added_cls"][None].expand(B, -1, D) + pos[0]
     M = 1 + add.shape[1]
-    x = ROUND(torch.cat([cls, add, pe.reshape(B, T * gh * gw, D)], dim=1))
+    x = ROUND.resid(torch.cat([cls, add, pe.reshape(B, T * gh * gw, D)], dim=1), (M, T, gh * gw))
     return x, (M, T, gh * gw)
 
 
@@ -245,7 +258,7 @@ def vision_tower(video: Tensor, sd: Dict[str, Tensor], cfg: OracleCfg, collect=N
     x, size = vip_embeddings(video, sd, cfg)
     if collect is not None:
         collect.append(x)
-    x = layer_norm(x, sd["vision_model.pre_layrnorm.weight"], sd["vision_model.pre_layrnorm.bias"])
+    x = layer_norm(x, sd["vision_model.pre_layrnorm.weight"], sd["vision_model.pre_layrnorm.bias"], resid_size=size)
     if collect is not None:
         collect.append(x)
     x = encoder(x, sd, "vision_model.encoder.", cfg.vision, size, None, collect)
@@ -258,8 +271,8 @@ def text_tower(ids: Tensor, mask: Optional[Tensor], sd: Dict[str, Tensor], cfg: 
     """CLIPTextTransformer.forward (CLIP_ViP.py:726-786): token+position gather (:210-227),
     causal+padding masks, encoder, final_layer_norm, pooled = hidden at ids.argmax(-1)."""
     B, Lt = ids.shape
-    x = ROUND(sd["text_model.embeddings.token_embedding.weight"][ids]
-              + sd["text_model.embeddings.position_embedding.weight"][:Lt][None])
+    x = ROUND.resid(sd["text_model.embeddings.token_embedding.weight"][ids]
+                    + sd["text_model.embeddings.position_embedding.weight"][:Lt][None], None)
     if collect is not None:
         collect.append(x)
     x = encoder(x, sd, "text_model.encoder.", cfg.text, None, mask, collect)

@@ -35,16 +35,17 @@ def bf16_round(t: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------------------- tolerances
 # ONE table for the end-to-end parity gates.  BASELINE.json:north_star states "within 1e-3 fp32 / 2e-2 bf16"
-# for logits / loss on identical inputs.  Every entry is <= 1.5 x the value MEASURED on MI355X (round 3, in brackets: batch 2 /
-# batch 8 of configs[1] where both exist), never above north_star's number where that number applies:
+# for logits / loss on identical inputs.  Every entry is <= 1.5 x the largest value MEASURED on MI355X over the cases that use it
+# (round 3, final build: fp32 side rows for the proxy tokens / the text stream), never above north_star's number where it applies:
 #   * unit-norm features and the cosine matrix (the logits before the learnable scale): ABSOLUTE, an order below 2e-2;
-#   * the loss: north_star's 2e-2 as a RELATIVE bound (`loss_rel`) everywhere, plus a per-case absolute bound.  At VidCLIP's logit
-#     scale e^4.6 ~ 100 a 3e-4 cosine error is a 3e-2 logit error: the reference's OWN torch.autocast(bfloat16) run differs from
-#     its fp32 run by 4.8e-3 / 2.2e-2 / 6.1e-3 / 7.3e-3 on configs[1] b2 / configs[3] / configs[4] / configs[1] b8 (fixtures,
-#     `ref_bf16`); this build by 3.4e-2 / 6.9e-3 / 6.3e-3 / 9.5e-3 -- the same population, batch 2 of configs[1] being the
-#     unlucky draw (1.9 % of its loss of 1.80; two diagonal logits dominate a 2 x 2 softmax).  At the bench batch of 8 pairs
-#     the deviation is 0.19 % of the loss.  The deviation of one case is itself a draw: it moved by 7e-3 on cfg1 when the
-#     attention forward kernel was replaced by one with the same arithmetic and different rounding points;
+#   * the loss: north_star's 2e-2 as a RELATIVE bound (`loss_rel`) everywhere (measured <= 0.98 %), plus an absolute bound.
+#     Measured |loss - fp32 reference|: cfg1 1.5e-3, configs[1] batch 2 4.0e-3, batch 8 1.6e-3, configs[3] 2.0e-2, configs[4] 1.5e-2;
+#     the reference's OWN torch.autocast(bfloat16) run differs from its fp32 run by 4.8e-3 / 7.3e-3 / 2.2e-2 / 6.1e-3 on the four
+#     full-size cases (fixtures, `ref_bf16`).  At VidCLIP's logit scale e^4.6 ~ 100 a 2e-4 cosine error is a 2e-2 logit error, and the
+#     deviation of one case moves by ~1e-2 between two correct builds (different rounding points, same arithmetic): the absolute
+#     bound is taken from the whole population, not from each case's last value.
+#     Before the side rows (bf16 residual stream everywhere) the same cases measured 7.9e-3 / 3.4e-2 .. 4.1e-2 / 9.5e-3 / 6.9e-3 / 6.3e-3
+#     with feature errors of 1.4-1.6e-3; tools/residual_precision_experiment.py predicted the gain on the CPU;
 #   * hidden states / gradients as max|a-b| / max|b| (tensor scale):
 #       *_emu  against the oracle that rounds to bf16 wherever the HIP path stores bf16 (values and activation gradients),
 #              TEACHER-FORCED per layer: same arithmetic, only accumulation order / fused epilogues differ -- the <= 2e-2 gates;
@@ -52,32 +53,28 @@ def bf16_round(t: torch.Tensor) -> torch.Tensor:
 # The entries above 2e-2 are (a) free-running trajectories (two bf16 realisations of a 12-layer network decorrelate: the oracle's
 # own bf16 emulation is as far from fp32 as this build is) and (b) `grad_emu_small` / `grad_ref_1d`: parameter gradients of the
 # 32-token text tower, sums of a few hundred signed bf16-rounded rows that largely cancel -- in the last layer only the pooled EOT
-# rows (2 at batch 2, 8 at batch 8) carry gradient.  Batch 8 brings the 1-D gradients vs the reference from 1.5e-1 to 8.2e-2 and
-# the bulk of the teacher-forced text gradients to 2-4e-2; the worst stays the last layer's v_proj / out_proj bias (6.5e-2: eight
-# rows).  The kernels underneath are held to 1e-2..2e-2 against fp64 in tests/test_attention_gpu.py / test_gemm_gpu.py.
+# rows (2 at batch 2, 8 at batch 8) carry gradient.  Batch 8 brings the 1-D gradients vs the reference from 1.4e-1 to 9.2e-2 and the
+# bulk of the teacher-forced text gradients to 2-4e-2; the worst stays a last-layer bias (7.5e-2: eight rows).  The kernels
+# underneath are held to 1e-2..2e-2 against fp64 in tests/test_attention_gpu.py / test_gemm_gpu.py.
 TOL = {
-    "features_abs": 2e-2,          # north_star's bound; only the tiny widened-weight fixture needs it (1.0e-2 measured)
-    "features_abs_full": 2.5e-3,   # |vis - ref|, |txt - ref| at every real architecture (cfg1..4): [1.44e-3 / 1.58e-3]
-    "cos_abs": 2.5e-3,             # |vis.txt^T - ref|: [8.5e-4 / 1.65e-3]
-    "loss_rel": 2e-2,              # |loss - fp32 reference| / |loss|, north_star's number: [1.87e-2 / 1.9e-3]
-    "loss_ref_abs": 5e-2,          # absolute, every batch-2 case: 6.3e-3 .. 3.4e-2 over cfg1 / configs[1] / [3] / [4] -- and the value of
-                                   # ONE case moves by ~1e-2 between two correct builds of this repo (cfg1: 7.9e-3 with the round-2
-                                   # attention forward, 1.5e-2 with the round-3 one: different rounding, same arithmetic), so the
-                                   # bound is 1.5 x the largest draw seen, not 1.5 x each case's last value
-    "loss_ref_abs_cfg2_b2": 5e-2,  # (kept as a name: configs[1] at batch 2, the 3.4e-2 draw)
+    "features_abs": 2e-2,          # north_star's bound; only the tiny widened-weight fixture needs more than 2e-3 (5.1e-3 measured)
+    "features_abs_full": 2e-3,     # |vis - ref|, |txt - ref| at every real architecture (cfg1..4, b8): vis <= 6.8e-4, txt <= 1.1e-3
+    "cos_abs": 1.5e-3,             # |vis.txt^T - ref|: <= 6.3e-4
+    "loss_rel": 2e-2,              # |loss - fp32 reference| / |loss|, north_star's number: <= 9.8e-3
+    "loss_ref_abs": 3e-2,          # absolute, every batch-2 case: <= 2.0e-2 (see above)
     "loss_abs": 2e-2,              # |loss - bf16-emulating oracle's loss|: two bf16 computations with the same storage points
     "fp32_abs": 1e-3,              # features and loss in fp32 compute mode (measured 2e-7 / 8.5e-6)
-    "hidden_emu": 1.2e-2,          # one layer on the HIP path's own input vs the emulating oracle layer: 9.4e-3 [8.3e-3 at b8]
+    "hidden_emu": 1.2e-2,          # one layer on the HIP path's own input vs the emulating oracle layer: <= 9.4e-3
     "hidden_emu_e2e": 3e-2,        # free-running 12-layer trajectories vs the emulation: 2.1e-2
     "hidden_ref": 3.5e-2,          # hidden-state rows vs reference fp32: 2.3e-2
-    "grad_emu": 2e-2,              # teacher-forced: dx and every video-tower parameter gradient: [1.65e-2 / 7.2e-3]
-    "grad_emu_small": 1e-1,        # teacher-forced text-tower parameter gradients: [6.8e-2 / 6.5e-2], bulk 2-4e-2 at batch 8
-    "grad_ref_2d": 7.5e-2,         # weight gradients vs reference fp32, free-running: 4.9e-2 (cfg1) [4.0e-2 / 4.6e-2]
-    "grad_ref_1d": 2e-1,           # 1-D gradients vs reference fp32, free-running: [1.53e-1 / 8.2e-2]
+    "grad_emu": 2e-2,              # teacher-forced: dx and every video-tower parameter gradient: <= 1.7e-2 (batch 8: 1.2e-2)
+    "grad_emu_small": 1e-1,        # teacher-forced text-tower parameter gradients: <= 6.6e-2 at batch 2, 7.5e-2 at batch 8 (bulk 2-4e-2)
+    "grad_ref_2d": 7.5e-2,         # weight gradients vs reference fp32, free-running: <= 5.0e-2
+    "grad_ref_1d": 2.5e-1,         # 1-D gradients vs reference fp32, free-running: <= 1.7e-1 at batch 2, 9.2e-2 at batch 8
 }
 # the same table at the bench batch (tests/golden/full_cfg2_b8.pt): better-conditioned sums (256 text rows / 18848 video rows)
-TOL_B8 = {"loss_ref_abs": 3e-2,            # 9.5e-3 measured at 8 pairs (0.19 %); batch-2 draws scatter by ~1e-2 between builds
-           "grad_emu": 1.1e-2, "grad_ref_1d": 1.25e-1, "grad_ref_2d": 7e-2, "hidden_emu": 1.2e-2}
+TOL_B8 = {"loss_ref_abs": 1.5e-2,          # 1.6e-3 measured at 8 pairs (0.03 %); the bound leaves room for the ~1e-2 scatter between builds
+          "grad_ref_1d": 1.4e-1, "grad_ref_2d": 7e-2}
 
 
 def loss_gate(loss: float, ref: float, abs_tol: float, rel_tol: float = None) -> bool:

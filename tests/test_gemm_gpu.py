@@ -352,3 +352,35 @@ def test_gemm256_persistent_tile_loop(M, N, K):
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, XPRETRAIN_GEMM256_PERSIST="0"),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "same" in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.parametrize("M,N,K,S,Ms,hint", [(18848, 768, 192, 2356, 4, 0), (18848, 768, 192, 2356, 4, 224), (4712, 768, 3072, 2356, 4, 0),
+                                             (200, 256, 128, 50, 3, 0), (40, 64, 64, 10, 4, 0)])
+def test_resid_epilogue_with_fp32_side_rows(M, N, K, S, Ms, hint):
+    """EPI_BIAS_RESID with the fp32 side rows of the residual stream (XpGemmDesc::resid_side / out_side): rows m with m % S < Ms take
+    their residual operand from the fp32 side buffer and leave their fp32 result there as well as the rounded C row; all other rows
+    are untouched by the feature.  256-wide family (both tile heights, K = 768-like and K = 3072) and the 128x128 family."""
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(M + N)
+    bf = torch.bfloat16
+    A, B = _mk((M, K), bf, 0.5), _mk((N, K), bf, 0.2)
+    bias = torch.randn(N, device="cuda")
+    R = _mk((M, N), bf)
+    nb = (M + S - 1) // S
+    rs = torch.randn(nb * Ms, N, device="cuda")
+    os_ = torch.full((nb * Ms, N), float("nan"), device="cuda")
+    C = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R, resid_side=rs, out_side=os_, side=(S, Ms), tile_rows_hint=hint)
+    plain = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_RESID, bias=bias, resid=R, tile_rows_hint=hint)
+    acc = A.double() @ B.double().t() + bias.double()
+    rows = torch.arange(M, device="cuda")
+    is_side = (rows % S) < Ms
+    sidx = (rows // S) * Ms + rows % S
+    # side rows: fp32 result = acc + bias + fp32 residual; C = that, rounded
+    want = acc[is_side] + rs[sidx[is_side]].double()
+    assert report("side rows fp32", os_[sidx[is_side]], want, 2e-5) <= 2e-5
+    assert torch.equal(C[is_side], os_[sidx[is_side]].to(bf))
+    assert torch.equal(C[~is_side], plain[~is_side])
+    # side slots of rows >= M (a partial last sample) stay untouched
+    touched = torch.zeros(nb * Ms, dtype=torch.bool, device="cuda"); touched[sidx[is_side]] = True
+    assert bool(torch.isnan(os_[~touched]).all())

@@ -94,3 +94,30 @@ def test_reduce_rows_batch_and_deferred_producers():
         assert torch.equal(dx0, dx1)
         assert report(f"ln dgamma deferred {dtype}", dg1, dg0, 2e-6) <= 2e-6
         assert report(f"ln dbeta deferred {dtype}", db1, db0, 2e-6) <= 2e-6
+
+
+@pytest.mark.parametrize("rows,S,M,stride", [(2 * 2356, 2356, 4, 4), (8, 1, 1, 4), (60, 10, 3, 5)])
+def test_forward_with_fp32_side_rows(rows, S, M, stride):
+    """xp_layernorm_fwd_side: rows r with r % S < M are read from the fp32 side buffer (row (r // S) * stride + r % S) instead of the
+    bf16 x, and -- on request -- their fp32 result is written to a second side buffer (pre_layrnorm: its output is the stream)."""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(rows)
+    cols = 768
+    x = torch.randn(rows, cols, device="cuda").to(torch.bfloat16)
+    nb = (rows + S - 1) // S
+    xs = torch.randn(nb * stride, cols, device="cuda") * 1.5 + 0.3
+    ys = torch.full_like(xs, float("nan"))
+    g, b = torch.randn(cols, device="cuda"), torch.randn(cols, device="cuda")
+    y, mean, rstd = H.layernorm_fwd(x, g, b, rows, cols, x_side=xs, y_side=ys, side=(S, M, stride))
+    y0, mean0, rstd0 = H.layernorm_fwd(x, g, b, rows, cols)
+    r = torch.arange(rows, device="cuda")
+    is_side, sidx = (r % S) < M, (r // S) * stride + r % S
+    assert torch.equal(y[~is_side], y0[~is_side]) and torch.equal(mean[~is_side], mean0[~is_side])
+    ref = torch.nn.functional.layer_norm(xs[sidx[is_side]].double(), (cols,), g.double(), b.double(), 1e-5)
+    assert report("ln side rows fp32 out", ys[sidx[is_side]], ref, 2e-5) <= 2e-5
+    assert torch.equal(y[is_side], ys[sidx[is_side]].to(torch.bfloat16))
+    assert report("ln side rows mean", mean[is_side], xs[sidx[is_side]].double().mean(1), 1e-5, scale_floor=1e-2) <= 1e-5
+    touched = torch.zeros(nb * stride, dtype=torch.bool, device="cuda"); touched[sidx[is_side]] = True
+    assert bool(torch.isnan(ys[~touched]).all())
+    y1, _, _ = H.layernorm_fwd(x, g, b, rows, cols, x_side=xs, side=(S, M, stride))       # read-only form
+    assert torch.equal(y1, y)

@@ -21,7 +21,7 @@ def source_stamp(root=ROOT):
 
 
 # grid sizes (threads) of the probe's launches: tiles * 512 threads
-VARIANT = {"gemm256_persist_kernel<3>": "NT_fc1_fwd", "gemm256_kernel<false, false": "NT_fc1_fwd", "gemm256_kernel<false, true": "NS_dpre_dx",
+VARIANT = {"gemm256_persist_kernel<": "NT_fc1_fwd", "gemm256_kernel<false, false": "NT_fc1_fwd", "gemm256_kernel<false, true": "NS_dpre_dx",
            "gemm256_kernel<true, true": "SS_dw1"}
 
 if __name__ == "__main__":

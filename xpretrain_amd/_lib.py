@@ -39,7 +39,8 @@ class XpGemmDesc(C.Structure):
         ("aux", vp), ("ldaux", i64),
         ("tab1", vp), ("tab2", vp), ("tab_L", i64),
         ("colsum_partials", vp),
-        ("tile_rows_hint", i32), ("reserved0", i32),
+        ("tile_rows_hint", i32), ("side_M", i32),
+        ("resid_side", vp), ("out_side", vp), ("side_S", i64),
     ]
 
 
@@ -61,7 +62,7 @@ class XpLayerFwd(C.Structure):
                 + [(n, vp) for n in ("x", "Wqkv", "Wo", "W1", "W2", "ln1_w", "ln1_b", "bqkv", "bo", "ln2_w", "ln2_b", "b1", "b2",
                                      "pad_mask", "h1", "qkv", "attn_o", "x2", "h2", "pre", "act", "x3", "mean1", "rstd1",
                                      "mean2", "rstd2", "stats", "workspace")]
-                + [("workspace_bytes", sz)])
+                + [("workspace_bytes", sz), ("side_in", vp), ("side_out", vp), ("side_S", i64), ("side_M", i32), ("reserved", i32)])
 
 
 class XpLayerBwd(C.Structure):
@@ -104,6 +105,7 @@ SIGNATURES = {
     "xp_colsum_workspace_bytes": (sz, [i64, i64]),
     "xp_colsum": (i32, [vp, i64, i64, i64, i32, vp, i32, vp, sz, vp]),
     "xp_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, i32, vp]),
+    "xp_layernorm_fwd_side": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, i32, vp, vp, i64, i32, i32, vp]),
     "xp_layernorm_bwd_workspace_bytes": (sz, [i64, i64]),
     "xp_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i64, i64, i32, vp, sz, vp]),
     "xp_attn_workspace_bytes": (sz, [i32, i64, i64, i64, i64, i64]),

@@ -573,6 +573,11 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
   kp.fast_epi = (kp.wide && xp_gemm_fast_epi_ok(d)) ? 1 : 0;
   kp.colsum = d->colsum_partials;
+  kp.rside = d->resid_side; kp.oside = d->out_side; kp.side_S = (unsigned)d->side_S; kp.side_M = (unsigned)d->side_M;
+  if (d->resid_side || d->out_side)
+    XP_REQUIRE(d->resid_side && d->out_side && ep == XP_EPI_BIAS_RESID && d->out_dtype == d->in_dtype && d->c_grp == 0 &&
+               d->side_S > 0 && d->side_M > 0 && d->side_M <= d->side_S && d->M + 512 < ((int64_t)1 << 24) && d->N % 8 == 0,
+               "xp_gemm: resid_side / out_side need both pointers, EPI_BIAS_RESID, an unmapped output, 0 < side_M <= side_S, M < 2^24");
   if (d->colsum_partials)
     XP_REQUIRE(xp_gemm_colsum_rows(d) > 0, "xp_gemm: fused column sums are not available for this problem "
                "(xp_gemm_colsum_rows() == 0): use xp_colsum / xp_colsum_partials");

@@ -181,7 +181,8 @@ struct DirectEpi {
   unsigned ld_c, ld_x;          // row pitch in bytes
   unsigned col_c[NG], col_x[NG];  // byte offset of the first column of the lane's column group, or EPI_OOB
   bool keep_aux;
-  __device__ __forceinline__ DirectEpi(const KParams& p, void* Cbase, int64_t n) {
+  SideRows side; int64_t ncol;    // fp32 side rows of the residual stream (gemm_common.h), first column of group 0
+  __device__ __forceinline__ DirectEpi(const KParams& p, void* Cbase, int64_t n) : side(p), ncol(n) {
     keep_aux = p.aux != nullptr;             // BIAS_GELU without aux: forward-only, the pre-activation is not stored
     rc = __builtin_amdgcn_make_buffer_rsrc(Cbase, 0, (unsigned)(p.M * p.ldc * OSZ), 0x00020000);
     ld_c = (unsigned)(p.ldc * OSZ);
@@ -217,8 +218,16 @@ struct DirectEpi {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
     } else if constexpr (EPI == XP_EPI_BIAS_RESID) {
-      const f32x8 r = raw8_f32<T>(pre);
-      v.lo += r.lo; v.hi += r.hi;
+      int64_t sb;
+      if (side.on() && col_c[hb] != EPI_OOB && side.hit(m, sb)) {   // fp32 side row (rare, divergent): fp32 residual operand + result
+        const int64_t n = ncol + hb * GSTRIDE;
+        const f32x8 r = load8(side.rin + sb + n);
+        v.lo += r.lo; v.hi += r.hi;
+        store8(side.out + sb + n, v);
+      } else {
+        const f32x8 r = raw8_f32<T>(pre);
+        v.lo += r.lo; v.hi += r.hi;
+      }
     } else if constexpr (EPI == XP_EPI_GELU_BWD) {
       const f32x8 r = raw8_f32<T>(pre);
 #pragma unroll

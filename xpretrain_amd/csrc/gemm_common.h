@@ -28,9 +28,30 @@ struct KParams {
   int wide;                  // 1: N, ldc, ldr, ldaux all multiples of 8 -> 8 columns per lane, 16-byte bf16 stores
   int fast_epi;              // 1: wide, identity cmap, C / resid / aux each < 4 GiB -> branch-free buffer-addressed epilogue
   float* colsum;             // optional [2 * tiles_m][N] column sums of the finished outputs per wave row block (256 family)
+  const float* rside; float* oside; unsigned side_S, side_M;   // BIAS_RESID: fp32 side rows of the residual stream (XpGemmDesc)
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
 };
 
+
+// fp32 side rows of the residual stream (XpGemmDesc::resid_side / out_side): output row m is a side row iff m % S < M; its side
+// index is (m / S) * M + m % S.  The video tower's M proxy tokens of every sample are kept in fp32 beside the bf16 stream: the
+// pooled feature is token 0 of the last layer, and rounding ITS residual stream to bf16 at every add is half of the feature error of
+// the whole bf16 path (tools/residual_precision_experiment.py) -- 4 rows of 2356.
+struct SideRows {
+  const float* rin; float* out; unsigned S, M; int64_t N, rows; float inv_S;
+  __device__ __forceinline__ SideRows(const KParams& p)
+      : rin(p.rside), out(p.oside), S(p.side_S), M(p.side_M), N(p.N), rows(p.M), inv_S(1.0f / (float)p.side_S) {}
+  __device__ __forceinline__ bool on() const { return rin != nullptr; }
+  // m / S by a float reciprocal + one correction step (m < 2^24: exact in fp32; the launcher checks) -- a handful of instructions
+  // per row instead of an integer division in every epilogue pass
+  __device__ __forceinline__ bool hit(unsigned m, int64_t& base) const {
+    unsigned q = (unsigned)((float)m * inv_S);
+    int rem = (int)m - (int)(q * S);
+    if (rem < 0) { --q; rem += (int)S; } else if (rem >= (int)S) { ++q; rem -= (int)S; }
+    base = ((int64_t)q * M + rem) * N;
+    return (unsigned)rem < M && (int64_t)m < rows;
+  }
+};
 
 // Per-lane epilogue constants: the lane owns columns n .. n+3 of every row it stores.
 struct EpiLane {
@@ -56,7 +77,10 @@ __device__ __forceinline__ void epi_row(const KParams& p, const EpiLane& el, f32
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
   } else if (ep == XP_EPI_BIAS_RESID) {
-    v += load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+    const SideRows sr(p);
+    int64_t sb;
+    if (sr.on() && sr.hit((unsigned)m, sb)) { v += load4(sr.rin + sb + n); store4(sr.out + sb + n, v); }
+    else v += load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
   } else if (ep == XP_EPI_GELU_BWD) {
     const f32x4 pre = load4(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
 #pragma unroll
@@ -90,8 +114,16 @@ __device__ __forceinline__ void epi_row8(const KParams& p, const EpiLane8& el, f
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
   } else if (ep == XP_EPI_BIAS_RESID) {
-    const f32x8 r = load8(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
-    v.lo += r.lo; v.hi += r.hi;
+    const SideRows sr(p);
+    int64_t sb;
+    if (sr.on() && sr.hit((unsigned)m, sb)) {
+      const f32x8 r = load8(sr.rin + sb + n);
+      v.lo += r.lo; v.hi += r.hi;
+      store8(sr.out + sb + n, v);
+    } else {
+      const f32x8 r = load8(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
+      v.lo += r.lo; v.hi += r.hi;
+    }
   } else if (ep == XP_EPI_GELU_BWD) {
     const f32x8 pre = load8(reinterpret_cast<const T*>(p.resid) + crow * p.ldr + n);
 #pragma unroll
@@ -160,8 +192,9 @@ struct FastEpi {
   unsigned ld_c, ld_x;      // row pitch in bytes
   unsigned col_c, col_x;    // byte offset of column n
   bool ok, keep_aux;
-  __device__ __forceinline__ FastEpi(const KParams& p, void* Cbase, int64_t n) {
-    ok = n < p.N;
+  SideRows side; int64_t ncol;
+  __device__ __forceinline__ FastEpi(const KParams& p, void* Cbase, int64_t n) : side(p) {
+    ok = n < p.N; ncol = ok ? n : 0;
     keep_aux = p.aux != nullptr;             // BIAS_GELU without aux: forward-only, the pre-activation is not stored
     const int64_t nn = ok ? n : 0;
     rc = __builtin_amdgcn_make_buffer_rsrc(Cbase, 0, (unsigned)(p.M * p.ldc * OSZ), 0x00020000);
@@ -188,8 +221,15 @@ struct FastEpi {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
     } else if constexpr (EPI == XP_EPI_BIAS_RESID) {
-      const f32x8 r = raw8_f32<T>(pre);
-      v.lo += r.lo; v.hi += r.hi;
+      int64_t sb;
+      if (side.on() && ok && side.hit(m, sb)) {       // fp32 side row: residual operand and result in fp32 (rare, divergent)
+        const f32x8 r = load8(side.rin + sb + ncol);
+        v.lo += r.lo; v.hi += r.hi;
+        store8(side.out + sb + ncol, v);
+      } else {
+        const f32x8 r = raw8_f32<T>(pre);
+        v.lo += r.lo; v.hi += r.hi;
+      }
     } else if constexpr (EPI == XP_EPI_GELU_BWD) {
       const f32x8 r = raw8_f32<T>(pre);
 #pragma unroll

@@ -67,7 +67,9 @@ int check_dims(const char* name, const XpLayerDims& d) {
 
 extern "C" size_t xp_encoder_layer_fwd_workspace_bytes(const XpLayerDims* d) {
   if (!d) return 0;
-  return xp_attn_workspace_bytes(d->attn_mode, d->B, d->heads, d->M, d->N, d->L) + 256;
+  // + the fp32 side rows of x2 (video: the proxy tokens; text: every row), used when XpLayerFwd::side_in is given
+  const size_t side_rows = d->attn_mode == XP_ATTN_PROXY ? (size_t)d->B * d->M : (size_t)d->rows;
+  return align256(xp_attn_workspace_bytes(d->attn_mode, d->B, d->heads, d->M, d->N, d->L)) + align256(side_rows * d->D * sizeof(float)) + 256;
 }
 
 extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
@@ -81,8 +83,20 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
   const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
   const int dt = d.dtype;
   const int hint = a->pre ? 0 : 224;       // forward-only pass (no pre-activation kept): latency first -> 224-row GEMM tiles
+  // fp32 side rows of the residual stream (the M proxy tokens of every sample): x rows in side_in, x2 rows in the workspace,
+  // x3 rows in side_out
+  const bool sided = a->side_in != nullptr;
+  XP_REQUIRE(!sided || (a->side_out && dt == XP_BF16 && a->side_S > 0 && a->side_M > 0 && a->side_M <= a->side_S),
+             "xp_encoder_layer_fwd: side rows need side_in and side_out, bf16 and 0 < side_M <= side_S");
+  const size_t attn_ws = align256(xp_attn_workspace_bytes(d.attn_mode, d.B, d.heads, d.M, d.N, d.L));
+  const int64_t sS = a->side_S;
+  const int32_t sM = a->side_M;
+  XP_REQUIRE(!sided || a->workspace_bytes >= attn_ws + align256((size_t)(cdiv(rows, sS) * sM) * D * sizeof(float)),
+             "xp_encoder_layer_fwd: workspace too small for the side rows");
+  float* side_x2 = sided ? reinterpret_cast<float*>(static_cast<char*>(a->workspace) + attn_ws) : nullptr;
   // h1 = LN1(x)
-  if ((rc = xp_layernorm_fwd(a->x, D, a->ln1_w, a->ln1_b, a->h1, D, a->mean1, a->rstd1, rows, D, d.ln_eps, dt, st))) return rc;
+  if ((rc = xp_layernorm_fwd_side(a->x, D, a->ln1_w, a->ln1_b, a->h1, D, a->mean1, a->rstd1, rows, D, d.ln_eps, dt,
+                                  a->side_in, nullptr, sS, sM, sM, st))) return rc;
   // qkv = (h1 Wqkv^T + b), q columns scaled by dh^-0.5 (:341)
   XpGemmDesc g = gemm_desc(a->h1, a->Wqkv, a->qkv, rows, 3 * D, D, dt);
   g.epilogue = XP_EPI_BIAS_QSCALE; g.bias = a->bqkv; g.scale = d.q_scale; g.scale_cols = D; g.tile_rows_hint = hint;
@@ -92,8 +106,10 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
   // x2 = x + attn_o Wo^T + bo
   g = gemm_desc(a->attn_o, a->Wo, a->x2, rows, D, D, dt);
   g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->bo; g.resid = a->x; g.tile_rows_hint = hint;
+  if (sided) { g.resid_side = a->side_in; g.out_side = side_x2; g.side_S = sS; g.side_M = sM; }
   if ((rc = xp_gemm(&g, st))) return rc;
-  if ((rc = xp_layernorm_fwd(a->x2, D, a->ln2_w, a->ln2_b, a->h2, D, a->mean2, a->rstd2, rows, D, d.ln_eps, dt, st))) return rc;
+  if ((rc = xp_layernorm_fwd_side(a->x2, D, a->ln2_w, a->ln2_b, a->h2, D, a->mean2, a->rstd2, rows, D, d.ln_eps, dt,
+                                  side_x2, nullptr, sS, sM, sM, st))) return rc;
   // pre = h2 W1^T + b1 ; act = quick_gelu(pre)
   g = gemm_desc(a->h2, a->W1, a->act, rows, Dff, D, dt);
   g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre; g.tile_rows_hint = hint;
@@ -101,6 +117,7 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
   // x3 = x2 + act W2^T + b2
   g = gemm_desc(a->act, a->W2, a->x3, rows, D, Dff, dt);
   g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->b2; g.resid = a->x2; g.tile_rows_hint = hint;
+  if (sided) { g.resid_side = side_x2; g.out_side = a->side_out; g.side_S = sS; g.side_M = sM; }
   return xp_gemm(&g, st);
 }
 

@@ -12,11 +12,16 @@ namespace {
 constexpr int MAXJ = 4;          // cols <= 1024
 constexpr int WAVES = 4;
 
+// fp32 side rows of the residual stream (XpGemmDesc::resid_side): row r is a side row iff r % S < M; its side index is
+// (r / S) * stride + r % S.  xin: the row is READ from there (fp32) instead of x; yout: the fp32 result is ALSO written there
+// (the LayerNorm whose output is itself the residual stream: pre_layrnorm).
+struct LnSide { const float* xin; float* yout; unsigned S, M, stride; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y, int64_t ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int64_t rows, int cols, float eps) {
+                                                     int64_t rows, int cols, float eps, LnSide side) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nj = (cols + 255) >> 8;
   f32x4 gm[MAXJ], bt[MAXJ];
@@ -30,10 +35,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
   for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < rows; row += (int64_t)gridDim.x * WAVES) {
     f32x4 v[MAXJ];
     float s = 0.f;
+    int64_t srow = -1;                               // wave-uniform: one row per wave
+    if (side.xin || side.yout) {                     // 32-bit arithmetic (rows < 2^31, checked by the launcher)
+      const unsigned r = (unsigned)row, q = r / side.S, rem = r - q * side.S;
+      if (rem < side.M) srow = (int64_t)q * side.stride + rem;
+    }
+    const float* xs = (srow >= 0 && side.xin) ? side.xin + srow * cols : nullptr;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const int c = j * 256 + lane * 4;
-      if (j < nj && c < cols) { v[j] = load4(x + row * ldx + c); s += v[j][0] + v[j][1] + v[j][2] + v[j][3]; }
+      if (j < nj && c < cols) { v[j] = xs ? load4(xs + c) : load4(x + row * ldx + c); s += v[j][0] + v[j][1] + v[j][2] + v[j][3]; }
       else v[j] = f32x4{0, 0, 0, 0};
     }
     const float mu = wave_sum(s) * inv;
@@ -55,6 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * gm[j][e] + bt[j][e];
         store4(y + row * ldy + c, o);
+        if (srow >= 0 && side.yout) store4(side.yout + srow * cols + c, o);
       }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -222,16 +234,27 @@ inline int bwd_blocks(int64_t rows) { int64_t b = cdiv(rows, WAVES * 4); return 
 extern "C" int xp_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                                 float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype,
                                 void* stream) {
+  return xp_layernorm_fwd_side(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, cols, eps, dtype, nullptr, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int xp_layernorm_fwd_side(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                                     float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype,
+                                     const float* x_side, float* y_side, int64_t side_S, int32_t side_M, int32_t side_stride,
+                                     void* stream) {
   XP_REQUIRE(x && gamma && beta && y && mean && rstd, "xp_layernorm_fwd: null pointer");
+  XP_REQUIRE((!x_side && !y_side) || (side_S > 0 && side_M > 0 && side_M <= side_S && side_stride >= side_M && rows < ((int64_t)1 << 31) &&
+                                      side_S < ((int64_t)1 << 31)),
+             "xp_layernorm_fwd_side: side rows need 0 < side_M <= side_S and side_stride >= side_M");
+  const LnSide side{x_side, y_side, (unsigned)(side_S > 0 ? side_S : 1), (unsigned)side_M, (unsigned)side_stride};
   XP_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXJ * 256, "xp_layernorm_fwd: cols=%lld unsupported (need %%4==0, <=%d)",
              (long long)cols, MAXJ * 256);
   XP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "xp_layernorm_fwd: ld must be a multiple of 4");
   const int blocks = (int)(cdiv(rows, WAVES) < 4096 ? cdiv(rows, WAVES) : 4096);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == XP_BF16)
-    ln_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, (int)cols, eps);
+    ln_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, (int)cols, eps, side);
   else if (dtype == XP_F32)
-    ln_fwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, ldx, gamma, beta, (float*)y, ldy, mean, rstd, rows, (int)cols, eps);
+    ln_fwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, ldx, gamma, beta, (float*)y, ldy, mean, rstd, rows, (int)cols, eps, side);
   else XP_REQUIRE(false, "xp_layernorm_fwd: bad dtype %d", dtype);
   XP_CHECK_LAUNCH("xp_layernorm_fwd");
   return XP_OK;

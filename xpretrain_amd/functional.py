@@ -236,7 +236,7 @@ def _native_ok(x, vecs, mats, pad_mask) -> bool:
     return True
 
 
-def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True):
+def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True, side=None):
     dev = x.device
     arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
     x3 = torch.empty_like(x)
@@ -253,8 +253,13 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
     a.mean1, a.rstd1, a.mean2, a.rstd2 = base + off["mean1"], base + off["rstd1"], base + off["mean2"], base + off["rstd2"]
     a.stats = base + off["stats"]
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    side_out = None
+    if side is not None:
+        side_out = torch.empty_like(side)
+        a.side_in, a.side_out = side.data_ptr(), side_out.data_ptr()
+        a.side_S, a.side_M = (plan.dims.S, plan.dims.M) if plan.dims.attn_mode == L.ATTN_PROXY else (1, 1)
     L.check(L.lib().xp_encoder_layer_fwd(C.byref(a), H._stream()), "xp_encoder_layer_fwd")
-    return x3, arena
+    return x3, arena, side_out
 
 
 # Gradient sinks (distributed.GradBucketReducer(layout_groups=...)): flat fp32 buffers -- slices of the reducer's all-reduce
@@ -322,7 +327,7 @@ def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_ma
     return (dx, g.get("dln1_w"), g.get("dln1_b"),
             pick(dwqkv, 0, need[3]), pick(dbqkv, 0, need[4]), pick(dwqkv, 1, need[5]), pick(dbqkv, 1, need[6]),
             pick(dwqkv, 2, need[7]), pick(dbqkv, 2, need[8]), gw("dwo", (D, D)), g.get("dbo"), g.get("dln2_w"), g.get("dln2_b"),
-            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None, None)
+            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ encoder layer
@@ -334,8 +339,13 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2,
                 B: int, S: int, heads: int, size: Optional[Tuple[int, int, int]], pad_mask: Optional[torch.Tensor],
-                training: bool = True):
+                training: bool = True, side: Optional[torch.Tensor] = None):
+        """``side`` (fp32, bf16 compute only): the fp32 side rows of ``x`` (SideRows, csrc/gemm_common.h) -- [B*M, D], the proxy rows of
+        every sample, in the video tower; [B*S, D], the whole stream, in the text tower.  The call then returns ``(x3, side_out)``."""
         dt = x.dtype
+        if side is not None and (dt != torch.bfloat16 or side.dtype != torch.float32 or not side.is_contiguous() or side.device != x.device
+                                 or tuple(side.shape) != ((B * size[0] if size is not None else B * S), x.shape[1])):
+            raise TypeError("EncoderLayerFn: side rows must be a contiguous fp32 [B*M, D] (video) / [B*S, D] (text) tensor beside a bf16 stream")
         rows, D = x.shape
         Dff = w1.shape[0]
         dh = D // heads
@@ -347,8 +357,8 @@ class EncoderLayerFn(torch.autograd.Function):
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
         if LAYER_CALLS and _native_ok(x, (ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2), (Wqkv, Wo, W1, W2), pad_mask):
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
-            x3, arena = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask,
-                                          keep_pre=training)
+            x3, arena, side_out = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask,
+                                                    keep_pre=training, side=side)
             ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask)
             ctx.plan = plan
             if GRAD_SINKS:          # (data-parallel runs only) the layer's parameters in the flat gradient order
@@ -356,27 +366,39 @@ class EncoderLayerFn(torch.autograd.Function):
                 ctx.sink_key = grad_sink_key(ctx.sink_params)
             else:
                 ctx.sink_params, ctx.sink_key = (), None
+            if side is not None:
+                ctx.mark_non_differentiable(side_out)
+                return x3, side_out
             return x3
         ctx.plan = None
+        sd = None if side is None else ((S, size[0]) if size is not None else (1, 1))
+        side_x2 = None if side is None else torch.empty_like(side)
+        side_out = None if side is None else torch.empty_like(side)
 
         hint = 0 if training else 224       # forward-only pass: latency-first GEMM tiles (as csrc/layer.hip)
-        h1, mean1, rstd1 = H.layernorm_fwd(x, ln1_w, ln1_b, rows, D)
+        lns = None if side is None else ((S, size[0], size[0]) if size is not None else (1, 1, 1))
+        h1, mean1, rstd1 = H.layernorm_fwd(x, ln1_w, ln1_b, rows, D, x_side=side, side=lns)
         qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D, tile_rows_hint=hint)
         attn_o, stats = H.attn_fwd(qkv, B, S, heads, size=size, pad_mask=pad_mask)
-        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x, tile_rows_hint=hint)
-        h2, mean2, rstd2 = H.layernorm_fwd(x2, ln2_w, ln2_b, rows, D)
+        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x, tile_rows_hint=hint,
+                    resid_side=side, out_side=side_x2, side=sd)
+        h2, mean2, rstd2 = H.layernorm_fwd(x2, ln2_w, ln2_b, rows, D, x_side=side_x2, side=lns)
         pre = torch.empty((rows, Dff), dtype=dt, device=x.device) if training else None
         act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre, tile_rows_hint=hint)
-        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2, tile_rows_hint=hint)
+        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2, tile_rows_hint=hint,
+                    resid_side=side_x2, out_side=side_out, side=sd)
 
         if training:
             ctx.save_for_backward(x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
                                   Wqkv, Wo, W1, W2, pad_mask)
         ctx.meta = (B, S, heads, size, q_scale, D, Dff)
+        if side is not None:
+            ctx.mark_non_differentiable(side_out)
+            return x3, side_out
         return x3
 
     @staticmethod
-    def backward(ctx, dx3):
+    def backward(ctx, dx3, _dside=None):
         if ctx.plan is not None:
             x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask = ctx.saved_tensors
             if dx3.dtype != x.dtype or dx3.device != x.device or dx3.shape != x.shape:
@@ -429,7 +451,32 @@ class EncoderLayerFn(torch.autograd.Function):
         defer.flush()
         keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
         return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),
-                keep(12, dln2_b), dw1, db1, dw2, keep(16, db2), None, None, None, None, None, None)
+                keep(12, dln2_b), dw1, db1, dw2, keep(16, db2), None, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------ fp32 side rows (proxy tokens)
+# XPRETRAIN_PROXY_FP32=1 (default): the video tower's M proxy tokens of every sample keep their residual stream in fp32 beside the
+# bf16 rows ([B*M, D] fp32 "side rows": read by the LayerNorms, read / written by the residual GEMM epilogues).  Measured with the
+# oracle's storage emulation (tools/residual_precision_experiment.py): |loss - fp32 reference| at configs[1] batch 2 drops from
+# 4.4e-2 to 5.6e-3, the feature error halves -- the same as a fully fp32 residual stream, for 4 of 2356 rows.
+PROXY_SIDE = os.environ.get("XPRETRAIN_PROXY_FP32", "1") != "0"
+
+
+def proxy_side_rows(class_emb, added_cls, pos_w, B: int, M: int) -> torch.Tensor:
+    """[B*M, D] fp32: class_embedding / added_cls + position_embedding[0] (CLIP_ViP.py:187-191), exact"""
+    D = class_emb.shape[0]
+    side = torch.empty((B * M, D), dtype=torch.float32, device=class_emb.device)
+    return H.vip_proxy_rows(class_emb.detach(), added_cls.detach().contiguous(), pos_w.detach().contiguous(), side, B, M, M, D)
+
+
+def with_side_rows(x: torch.Tensor, side: Optional[torch.Tensor], B: int, S: int) -> torch.Tensor:
+    """hidden state for ``output_hidden_states``: with side rows, an fp32 copy of x whose proxy rows are the exact fp32 ones"""
+    if side is None:
+        return x
+    D = x.shape[1]
+    h = x.detach().float()
+    h.view(B, S, D)[:, :side.shape[0] // B] = side.view(B, -1, D)      # (text tower: the side rows are the whole stream)
+    return h
 
 
 # ------------------------------------------------------------------------------------------ embeddings
@@ -498,18 +545,24 @@ class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm (pre_layrnorm :881, post_layernorm :893, final_layer_norm :772)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, x_side=None, side=None, want_y_side=False):
+        """``x_side`` (fp32) with ``side = (S, M, stride)``: rows r with r % S < M are read from x_side (fp32 side rows of the
+        residual stream); ``want_y_side``: their fp32 result is returned too (``(y, y_side)``, y_side laid out like x_side)."""
         rows, D = x.shape
-        y, mean, rstd = H.layernorm_fwd(x, gamma.detach(), beta.detach(), rows, D)
+        y_side = torch.empty_like(x_side) if want_y_side else None
+        y, mean, rstd = H.layernorm_fwd(x, gamma.detach(), beta.detach(), rows, D, x_side=x_side, y_side=y_side, side=side)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        if want_y_side:
+            ctx.mark_non_differentiable(y_side)
+            return y, y_side
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dys=None):
         x, gamma, mean, rstd = ctx.saved_tensors
         rows, D = x.shape
         dx, dg, db = H.layernorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd, rows, D)
-        return dx, dg, db
+        return dx, dg, db, None, None, None
 
 
 class GatherRowsFn(torch.autograd.Function):
@@ -625,7 +678,8 @@ def _layer_params(layer):
     return tuple(d[k] for d in tabs for k in ("weight", "bias"))
 
 
-def encoder_layer(x, layer, B, S, heads, size, pad_mask):
-    """Apply ``EncoderLayerFn`` with the parameters of a ``CLIPEncoderLayer`` module."""
-    # last argument: forward-only passes (torch.no_grad: retrieval / inference) skip the MLP pre-activation
-    return EncoderLayerFn.apply(x, *_layer_params(layer), B, S, heads, size, pad_mask, torch.is_grad_enabled())
+def encoder_layer(x, layer, B, S, heads, size, pad_mask, side=None):
+    """Apply ``EncoderLayerFn`` with the parameters of a ``CLIPEncoderLayer`` module.  With ``side`` (the proxy rows of x in fp32)
+    returns ``(x3, side_out)``."""
+    # `training` argument: forward-only passes (torch.no_grad: retrieval / inference) skip the MLP pre-activation
+    return EncoderLayerFn.apply(x, *_layer_params(layer), B, S, heads, size, pad_mask, torch.is_grad_enabled(), side)

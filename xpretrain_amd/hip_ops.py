@@ -60,7 +60,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
          a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
          scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
          a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None, colsum_name="gemm_colsum",
-         tile_rows_hint=0):
+         tile_rows_hint=0, resid_side=None, out_side=None, side=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc.
 
     ``colsum_defer`` (a DeferredReduce): also return the column sums of C (a bias gradient), as ``(C, colsum)``; the
@@ -94,6 +94,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     d.tab2 = 0 if tab2 is None else _chk(tab2, "tab2", torch.float32).data_ptr()
     d.tab_L = tab_L
     d.tile_rows_hint = tile_rows_hint
+    if resid_side is not None or out_side is not None:       # fp32 side rows of the residual stream: side = (S, M)
+        _chk(resid_side, "resid_side", torch.float32); _chk(out_side, "out_side", torch.float32)
+        S_, M_ = side
+        need = ((M - 1) // S_ * M_ + min(M_, S_)) * N
+        if not (resid_side.is_contiguous() and out_side.is_contiguous()) or resid_side.numel() < need or out_side.numel() < need:
+            raise ValueError("gemm: resid_side / out_side are too small or not contiguous")
+        d.resid_side, d.out_side, d.side_S, d.side_M = resid_side.data_ptr(), out_side.data_ptr(), S_, M_
     if colsum_defer is None:
         L.check(L.lib().xp_gemm(C.byref(d), _stream()), "xp_gemm")
         return out
@@ -198,13 +205,26 @@ def colsum_deferred(X: torch.Tensor, rows: int, cols: int, defer: DeferredReduce
 
 # --------------------------------------------------------------------------------------- LayerNorm
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows: int, cols: int, ldx=None,
-                  eps: float = 1e-5):
+                  eps: float = 1e-5, x_side=None, y_side=None, side=None):
+    """``side = (S, M, stride)`` with ``x_side`` / ``y_side`` (fp32 [.., cols]): rows r with r % S < M are read from x_side
+    instead of x / also written in fp32 to y_side, at side row (r // S) * stride + r % S (xp_layernorm_fwd_side)."""
     _chk(x, "x"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
     y = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    L.check(L.lib().xp_layernorm_fwd(_p(x), ldx or cols, _p(gamma), _p(beta), _p(y), cols, _p(mean), _p(rstd),
-                                     rows, cols, eps, _dt(x), _stream()), "xp_layernorm_fwd")
+    if x_side is None and y_side is None:
+        L.check(L.lib().xp_layernorm_fwd(_p(x), ldx or cols, _p(gamma), _p(beta), _p(y), cols, _p(mean), _p(rstd),
+                                         rows, cols, eps, _dt(x), _stream()), "xp_layernorm_fwd")
+    else:
+        S, M, stride = side
+        for t, nm in ((x_side, "x_side"), (y_side, "y_side")):
+            if t is not None:
+                _chk(t, nm, torch.float32)
+                if not t.is_contiguous() or t.numel() < ((rows - 1) // S * stride + min(M, S)) * cols:
+                    raise ValueError(f"layernorm_fwd: {nm} is too small or not contiguous")
+        L.check(L.lib().xp_layernorm_fwd_side(_p(x), ldx or cols, _p(gamma), _p(beta), _p(y), cols, _p(mean), _p(rstd),
+                                              rows, cols, eps, _dt(x), _p(x_side), _p(y_side), S, M, stride, _stream()),
+                "xp_layernorm_fwd_side")
     return y, mean, rstd
 
 

@@ -217,8 +217,8 @@ class CLIPEncoderLayer(nn.Module):
         self.mlp = CLIPMLP(config)
         self.layer_norm2 = nn.LayerNorm(self.embed_dim)
 
-    def forward(self, hidden_states, B, S, inputs_size=None, pad_mask=None):
-        return XF.encoder_layer(hidden_states, self, B, S, self.num_heads, inputs_size, pad_mask)
+    def forward(self, hidden_states, B, S, inputs_size=None, pad_mask=None, side=None):
+        return XF.encoder_layer(hidden_states, self, B, S, self.num_heads, inputs_size, pad_mask, side)
 
 
 class CLIPEncoder(nn.Module):
@@ -230,12 +230,16 @@ class CLIPEncoder(nn.Module):
         self.layers = nn.ModuleList([CLIPEncoderLayer(config) for _ in range(config.num_hidden_layers)])
         self.gradient_checkpointing = False
 
-    def forward(self, x, B, S, inputs_size=None, pad_mask=None, collect=None):
+    def forward(self, x, B, S, inputs_size=None, pad_mask=None, collect=None, side=None):
+        """``side``: the proxy rows of ``x`` in fp32 (video tower, bf16 compute: XF.PROXY_SIDE); returns ``(x, side)`` then."""
         for layer in self.layers:
-            x = layer(x, B, S, inputs_size, pad_mask)
+            if side is None:
+                x = layer(x, B, S, inputs_size, pad_mask)
+            else:
+                x, side = layer(x, B, S, inputs_size, pad_mask, side)
             if collect is not None:
-                collect.append(x)
-        return x
+                collect.append(XF.with_side_rows(x, side, B, S))
+        return x if side is None else (x, side)
 
 
 # ------------------------------------------------------------------------------------------ towers
@@ -261,15 +265,26 @@ class CLIPTextTransformer(nn.Module):
         D = self.config.hidden_size
         x = self.embeddings(input_ids, position_ids, self.compute_dtype)
         pad = None if attention_mask is None else attention_mask.to(torch.int64).contiguous()
-        hs = [x] if output_hidden_states else None
-        x = self.encoder(x, B, Lt, None, pad, hs)
-        # LayerNorm is row-wise, so pooling the EOT rows first and normalising only those is identical to
-        # final_layer_norm followed by the gather (:772-776); the full normalised sequence is only produced
-        # on request.
         idx = XF.H.argmax_rows(input_ids)
         ln = self.final_layer_norm
-        pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias)
-        last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D))      # (:772) resolved on access
+        if XF.PROXY_SIDE and self.compute_dtype == torch.bfloat16:
+            # the text tower is 256 rows: its WHOLE residual stream is kept in fp32 beside the bf16 rows the kernels read (the same
+            # side-row mechanism as the video tower's proxy tokens, with every row a side row)
+            emb = self.embeddings
+            side = XF.H.text_embed_fwd(input_ids, emb.token_embedding.weight.detach(), emb.position_embedding.weight.detach(), torch.float32)
+            hs = [XF.with_side_rows(x, side, B, Lt)] if output_hidden_states else None
+            x, side = self.encoder(x, B, Lt, None, pad, hs, side)
+            pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias,
+                                          XF.H.gather_rows(side, idx, B, Lt, D), (1, 1, 1))
+            last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias, side, (1, 1, 1)).view(B, Lt, D))
+        else:
+            hs = [x] if output_hidden_states else None
+            x = self.encoder(x, B, Lt, None, pad, hs)
+            # LayerNorm is row-wise, so pooling the EOT rows first and normalising only those is identical to
+            # final_layer_norm followed by the gather (:772-776); the full normalised sequence is only produced
+            # on request.
+            pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias)
+            last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D))      # (:772) resolved on access
         out = BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled,
                                          hidden_states=None if hs is None else tuple(h.view(B, Lt, D) for h in hs),
                                          attentions=None)
@@ -296,12 +311,23 @@ class CLIPVisionTransformer(nn.Module):
         B = pixel_values.shape[0]
         D = self.config.hidden_size
         x, size = self.embeddings(pixel_values, self.compute_dtype)
-        S = size[0] + size[1] * size[2]
-        x = XF.LayerNormFn.apply(x, self.pre_layrnorm.weight, self.pre_layrnorm.bias)
-        hs = [x] if output_hidden_states else None
-        x = self.encoder(x, B, S, size, None, hs)
-        pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
-                                      self.post_layernorm.bias)
+        S, M = size[0] + size[1] * size[2], size[0]
+        if XF.PROXY_SIDE and self.compute_dtype == torch.bfloat16:
+            # the M proxy tokens of every sample travel through the residual stream in fp32 beside the bf16 rows (4 of 2356 rows:
+            # the pooled feature is proxy 0 of the last layer, and rounding its residual stream is half of the bf16 path's error)
+            emb = self.embeddings
+            side = XF.proxy_side_rows(emb.class_embedding, emb.added_cls, emb.position_embedding.weight, B, M)
+            x, side = XF.LayerNormFn.apply(x, self.pre_layrnorm.weight, self.pre_layrnorm.bias, side, (S, M, M), True)
+            hs = [XF.with_side_rows(x, side, B, S)] if output_hidden_states else None
+            x, side = self.encoder(x, B, S, size, None, hs, side)
+            pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
+                                          self.post_layernorm.bias, side, (1, 1, M))
+        else:
+            x = XF.LayerNormFn.apply(x, self.pre_layrnorm.weight, self.pre_layrnorm.bias)
+            hs = [x] if output_hidden_states else None
+            x = self.encoder(x, B, S, size, None, hs)
+            pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
+                                          self.post_layernorm.bias)
         out = BaseModelOutputWithPooling(last_hidden_state=x.view(B, S, D), pooler_output=pooled,
                                          hidden_states=None if hs is None else tuple(h.view(B, S, D) for h in hs),
                                          attentions=None)
