@@ -164,6 +164,19 @@ int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
                      void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                      int64_t rows, int64_t cols, int32_t dtype,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* The two backward forms with the fp32 side rows of x the forward normalised (xp_layernorm_fwd_side's x_side, same indexing): those
+ * rows' x-hat is recomputed from the fp32 values, so the backward differentiates exactly the function the forward computed. */
+int xp_layernorm_bwd_partials_side(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                                   const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                                   void* dx, int64_t lddx, int32_t with_dx_colsum, int64_t rows, int64_t cols,
+                                   int32_t dtype, const float* x_side, int64_t side_S, int32_t side_M, int32_t side_stride,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int xp_layernorm_bwd_side(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                          const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                          void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                          int64_t rows, int64_t cols, int32_t dtype,
+                          const float* x_side, int64_t side_S, int32_t side_M, int32_t side_stride,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------------------------------- Attention
  * Fused attention on the packed projection output qkv[B, S, 3, H, 64] (row stride ldqkv elements; q is
@@ -336,9 +349,11 @@ typedef struct XpLayerFwd {
   /* optional (bf16): fp32 side rows of the residual stream -- rows r with r % side_S < side_M, stored at side row
    * (r / side_S) * side_M + r % side_S of a [.., D] fp32 buffer: the M proxy tokens of every video sample (side_S = S, side_M = M),
    * or the whole stream of the small text tower (side_S = side_M = 1).  side_in = those rows of x in fp32 (read by LayerNorm 1 and as
-   * out_proj's residual operand), side_out = those rows of x3 in fp32 (the intermediate x2 rows live in the workspace).  Both NULL:
-   * plain bf16 stream.  See XpGemmDesc::resid_side. */
+   * out_proj's residual operand), side_out = those rows of x3 in fp32, side_x2 = those rows of the intermediate x2 (kept for the
+   * backward's second LayerNorm; NULL: they live in the workspace, forward-only pass).  side_in NULL: plain bf16 stream.  See
+   * XpGemmDesc::resid_side. */
   const float* side_in; float* side_out; int64_t side_S; int32_t side_M; int32_t reserved;
+  float* side_x2;
 } XpLayerFwd;
 size_t xp_encoder_layer_fwd_workspace_bytes(const XpLayerDims* dims);
 int xp_encoder_layer_fwd(const XpLayerFwd* args, void* stream);
@@ -356,6 +371,8 @@ typedef struct XpLayerBwd {
   float* dln1_w; float* dln1_b; float* dwqkv; float* dbqkv; float* dwo; float* dbo;
   float* dln2_w; float* dln2_b; float* dw1; float* db1; float* dw2; float* db2;
   void* workspace; size_t workspace_bytes;                                /* >= xp_encoder_layer_bwd_workspace_bytes */
+  /* optional: the forward's fp32 side rows of x (side_in) and x2 (side_x2), read by the two LayerNorm backward passes */
+  const float* side_in; const float* side_x2; int64_t side_S; int32_t side_M; int32_t reserved;
 } XpLayerBwd;
 size_t xp_encoder_layer_bwd_workspace_bytes(const XpLayerDims* dims);
 int xp_encoder_layer_bwd(const XpLayerBwd* args, void* stream);

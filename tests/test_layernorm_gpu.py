@@ -121,3 +121,43 @@ def test_forward_with_fp32_side_rows(rows, S, M, stride):
     assert bool(torch.isnan(ys[~touched]).all())
     y1, _, _ = H.layernorm_fwd(x, g, b, rows, cols, x_side=xs, side=(S, M, stride))       # read-only form
     assert torch.equal(y1, y)
+
+
+@pytest.mark.parametrize("rows,S,M,stride", [(2 * 2356, 2356, 4, 4), (8, 1, 1, 1), (60, 10, 3, 5)])
+def test_backward_with_fp32_side_rows(rows, S, M, stride):
+    """xp_layernorm_bwd_side / _partials_side: the rows the forward normalised from the fp32 side buffer get their x-hat from the same
+    fp32 values in the backward (fp64 autograd of the mixed-precision input as reference); the other rows are bit-identical to the
+    plain kernel; both launch forms (immediate and deferred partial rows) agree."""
+    from xpretrain_amd import hip_ops as H
+    torch.manual_seed(rows + 1)
+    cols = 768
+    x = torch.randn(rows, cols, device="cuda").to(torch.bfloat16)
+    nb = (rows + S - 1) // S
+    xs = torch.randn(nb * stride, cols, device="cuda") * 1.5 + 0.3
+    g, b = torch.randn(cols, device="cuda"), torch.randn(cols, device="cuda")
+    dy = torch.randn(rows, cols, device="cuda").to(torch.bfloat16)
+    dres = torch.randn(rows, cols, device="cuda").to(torch.bfloat16)
+    side = (S, M, stride)
+    _, mean, rstd = H.layernorm_fwd(x, g, b, rows, cols, x_side=xs, side=side)
+    dx, dg, db = H.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dres=dres, x_side=xs, side=side)
+    dx0, dg0, db0 = H.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dres=dres)
+    r = torch.arange(rows, device="cuda")
+    is_side, sidx = (r % S) < M, (r // S) * stride + r % S
+    assert torch.equal(dx[~is_side], dx0[~is_side])
+    assert not torch.equal(dx[is_side], dx0[is_side])           # the bf16 x of those rows is unrelated noise here
+    xin = x.double()
+    xin[is_side] = xs[sidx[is_side]].double()
+    xin.requires_grad_(True)
+    gd = g.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xin, (cols,), gd, bd, 1e-5).backward(dy.double())
+    assert report("ln bwd side rows dx", dx[is_side], xin.grad[is_side] + dres[is_side].double(), 1.5e-2) <= 1.5e-2   # bf16 output
+    assert report("ln bwd side dgamma", dg, gd.grad, 2e-5) <= 2e-5
+    assert report("ln bwd side dbeta", db, bd.grad, 2e-5) <= 2e-5
+    d = H.DeferredReduce(x.device)
+    dx1, dg1, db1, dxs, drs = H.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dres=dres, defer=d, dx_colsum=True, dres_colsum=True,
+                                              name="ln_side", x_side=xs, side=side)
+    d.flush()
+    assert torch.equal(dx1, dx)
+    assert report("ln bwd side dgamma (deferred)", dg1, dg, 2e-6) <= 2e-6
+    assert report("ln bwd side dx colsum", dxs, dx.double().sum(0), 3e-3) <= 3e-3

@@ -62,7 +62,8 @@ class XpLayerFwd(C.Structure):
                 + [(n, vp) for n in ("x", "Wqkv", "Wo", "W1", "W2", "ln1_w", "ln1_b", "bqkv", "bo", "ln2_w", "ln2_b", "b1", "b2",
                                      "pad_mask", "h1", "qkv", "attn_o", "x2", "h2", "pre", "act", "x3", "mean1", "rstd1",
                                      "mean2", "rstd2", "stats", "workspace")]
-                + [("workspace_bytes", sz), ("side_in", vp), ("side_out", vp), ("side_S", i64), ("side_M", i32), ("reserved", i32)])
+                + [("workspace_bytes", sz), ("side_in", vp), ("side_out", vp), ("side_S", i64), ("side_M", i32), ("reserved", i32),
+                   ("side_x2", vp)])
 
 
 class XpLayerBwd(C.Structure):
@@ -71,7 +72,7 @@ class XpLayerBwd(C.Structure):
                                      "ln2_w", "mean1", "rstd1", "mean2", "rstd2", "stats", "pad_mask", "dx3", "dx",
                                      "dln1_w", "dln1_b", "dwqkv", "dbqkv", "dwo", "dbo", "dln2_w", "dln2_b", "dw1", "db1",
                                      "dw2", "db2", "workspace")]
-                + [("workspace_bytes", sz)])
+                + [("workspace_bytes", sz), ("side_in", vp), ("side_x2", vp), ("side_S", i64), ("side_M", i32), ("reserved", i32)])
 
 
 class XpAdamTensor(C.Structure):
@@ -107,6 +108,10 @@ SIGNATURES = {
     "xp_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, i32, vp]),
     "xp_layernorm_fwd_side": (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, i32, vp, vp, i64, i32, i32, vp]),
     "xp_layernorm_bwd_workspace_bytes": (sz, [i64, i64]),
+    "xp_layernorm_bwd_partials_side": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i64, i64, i32, vp, i64, i32, i32,
+                                             vp, sz, vp]),
+    "xp_layernorm_bwd_side": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i64, i64, i32, vp, i64, i32, i32,
+                                    vp, sz, vp]),
     "xp_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i64, i64, i32, vp, sz, vp]),
     "xp_attn_workspace_bytes": (sz, [i32, i64, i64, i64, i64, i64]),
     "xp_attn_fwd": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, sz, vp]),

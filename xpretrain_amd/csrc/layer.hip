@@ -93,7 +93,7 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
   const int32_t sM = a->side_M;
   XP_REQUIRE(!sided || a->workspace_bytes >= attn_ws + align256((size_t)(cdiv(rows, sS) * sM) * D * sizeof(float)),
              "xp_encoder_layer_fwd: workspace too small for the side rows");
-  float* side_x2 = sided ? reinterpret_cast<float*>(static_cast<char*>(a->workspace) + attn_ws) : nullptr;
+  float* side_x2 = !sided ? nullptr : a->side_x2 ? a->side_x2 : reinterpret_cast<float*>(static_cast<char*>(a->workspace) + attn_ws);
   // h1 = LN1(x)
   if ((rc = xp_layernorm_fwd_side(a->x, D, a->ln1_w, a->ln1_b, a->h1, D, a->mean1, a->rstd1, rows, D, d.ln_eps, dt,
                                   a->side_in, nullptr, sS, sM, sM, st))) return rc;
@@ -175,6 +175,9 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
   XP_REQUIRE(a->x && a->h1 && a->qkv && a->attn_o && a->x2 && a->h2 && a->pre && a->act && a->Wqkv && a->Wo && a->W1 && a->W2 &&
              a->ln1_w && a->ln2_w && a->mean1 && a->rstd1 && a->mean2 && a->rstd2 && a->stats && a->dx3 && a->dx,
              "xp_encoder_layer_bwd: null pointer");
+  XP_REQUIRE((!a->side_in && !a->side_x2) || (a->side_in && a->side_x2 && d.dtype == XP_BF16 && a->side_S > 0 && a->side_M > 0 &&
+                                               a->side_M <= a->side_S),
+             "xp_encoder_layer_bwd: side rows need side_in and side_x2, bf16 and 0 < side_M <= side_S");
   const BwdPlan p = plan_bwd(d);
   XP_REQUIRE(a->workspace && a->workspace_bytes >= p.total, "xp_encoder_layer_bwd: workspace too small (%zu < %zu)",
              a->workspace_bytes, p.total);
@@ -208,8 +211,8 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
   if ((rc = xp_gemm(&g, st))) return rc;
   if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, st))) return rc;
   // dx2 = dx3 + LN2'(dh2); partial rows [dgamma | dbeta | colsum(dx2) | colsum(dx3)] -- out_proj's and fc2's bias gradients
-  if ((rc = xp_layernorm_bwd_partials(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 2, rows, D, dt,
-                                      ln2_part, p.ln2, st))) return rc;
+  if ((rc = xp_layernorm_bwd_partials_side(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 2, rows, D, dt,
+                                           a->side_x2, a->side_S, a->side_M, a->side_M, ln2_part, p.ln2, st))) return rc;
   df.add(ln2_part, a->dln2_w, 4 * D, (int)p.ln_rows, (int)D);
   df.add(ln2_part + D, a->dln2_b, 4 * D, (int)p.ln_rows, (int)D);
   df.add(ln2_part + 2 * D, a->dbo, 4 * D, (int)p.ln_rows, (int)D);
@@ -229,8 +232,8 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
     if (!p.cs_qkv_fused && (rc = xp_colsum_partials(dqkv, rows, 3 * D, 3 * D, dt, cs_qkv, p.cs_qkv, st))) return rc;
     df.add(cs_qkv, a->dbqkv, 3 * D, (int)p.cs_qkv_rows, (int)(3 * D));
   }
-  if ((rc = xp_layernorm_bwd_partials(dh1, D, a->x, D, a->ln1_w, a->mean1, a->rstd1, dx2, D, a->dx, D, 0, rows, D, dt,
-                                      ln1_part, p.ln1, st))) return rc;
+  if ((rc = xp_layernorm_bwd_partials_side(dh1, D, a->x, D, a->ln1_w, a->mean1, a->rstd1, dx2, D, a->dx, D, 0, rows, D, dt,
+                                           a->side_in, a->side_S, a->side_M, a->side_M, ln1_part, p.ln1, st))) return rc;
   df.add(ln1_part, a->dln1_w, 2 * D, (int)p.ln_rows, (int)D);
   df.add(ln1_part + D, a->dln1_b, 2 * D, (int)p.ln_rows, (int)D);
   if (df.n) {

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __res
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* dres, int64_t lddres,
                                                      T* dx, int64_t lddx, float* __restrict__ part,
-                                                     int64_t rows, int cols) {
+                                                     int64_t rows, int cols, LnSide side) {
   constexpr int NV = 2 + DXS;
   __shared__ float red[WAVES][NV][NJ * 256];
   typedef typename Raw4<T>::type raw_t;
@@ -117,10 +117,15 @@ __global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __res
     const int64_t rws[2] = {row0, row0 + stride};
     raw_t xr[2][NJ], dr[2][NJ], rr[2][NJ];
     float mu[2], rs[2];
+    const float* xs[2] = {nullptr, nullptr};          // fp32 side row of x (wave-uniform): the forward normalised THAT row
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const bool ok = rws[u] < rows;
       mu[u] = ok ? mean[rws[u]] : 0.f; rs[u] = ok ? rstd[rws[u]] : 0.f;
+      if (side.xin && ok) {
+        const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)rws[u]), q = r / side.S, rem = r - q * side.S;
+        if (rem < side.M) xs[u] = side.xin + ((int64_t)q * side.stride + rem) * cols;
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int c = j * 256 + lane * 4;
@@ -138,7 +143,8 @@ __global__ __launch_bounds__(256) XP_NO_PK_F32 void ln_bwd_kernel(const T* __res
       f32x4 xh[NJ], gy[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const f32x4 xv = cvt4(xr[u][j]), dv = cvt4(dr[u][j]);
+        const int cx = j * 256 + lane * 4;
+        const f32x4 xv = (xs[u] && cx < cols) ? load4(xs[u] + cx) : cvt4(xr[u][j]), dv = cvt4(dr[u][j]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[j][e] = (xv[e] - mu[u]) * rs[u];
@@ -267,8 +273,13 @@ extern "C" size_t xp_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
 namespace {
 int ln_bwd_launch(const char* name, const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, int64_t lddres, void* dx, int64_t lddx, int64_t rows, int64_t cols,
-                  int32_t dtype, int dxs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                  int32_t dtype, int dxs, void* workspace, size_t workspace_bytes, hipStream_t st, const float* x_side = nullptr,
+                  int64_t side_S = 0, int32_t side_M = 0, int32_t side_stride = 0) {
   XP_REQUIRE(dy && x && gamma && mean && rstd && dx, "%s: null pointer", name);
+  XP_REQUIRE(!x_side || (side_S > 0 && side_M > 0 && side_M <= side_S && side_stride >= side_M && rows < ((int64_t)1 << 31) &&
+                         side_S < ((int64_t)1 << 31)),
+             "%s: side rows need 0 < side_M <= side_S and side_stride >= side_M", name);
+  const LnSide side{x_side, nullptr, (unsigned)(side_S > 0 ? side_S : 1), (unsigned)side_M, (unsigned)side_stride};
   XP_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXJ * 256, "%s: cols=%lld unsupported", name, (long long)cols);
   XP_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "%s: ld must be a multiple of 4", name);
   XP_REQUIRE(workspace && workspace_bytes >= xp_layernorm_bwd_workspace_bytes(rows, cols), "%s: workspace too small", name);
@@ -279,7 +290,7 @@ int ln_bwd_launch(const char* name, const void* dy, int64_t lddy, const void* x,
   const int nj = (int)cdiv(cols, 256);
 #define XP_LN_BWD(T, NJ, D)                                                                                           \
   ln_bwd_kernel<T, NJ, D><<<blocks, 256, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, gamma, mean, rstd, (const T*)dres, \
-                                                  lddres, (T*)dx, lddx, part, rows, (int)cols)
+                                                  lddres, (T*)dx, lddx, part, rows, (int)cols, side)
 #define XP_LN_BWD_NJ(T, D)                                                                                            \
   do { if (nj == 1) XP_LN_BWD(T, 1, D); else if (nj == 2) XP_LN_BWD(T, 2, D); else if (nj == 3) XP_LN_BWD(T, 3, D); else XP_LN_BWD(T, 4, D); } while (0)
   if (dtype == XP_BF16) { if (dxs == 2) XP_LN_BWD_NJ(bf16_t, 2); else if (dxs) XP_LN_BWD_NJ(bf16_t, 1); else XP_LN_BWD_NJ(bf16_t, 0); }
@@ -296,10 +307,20 @@ extern "C" int xp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                                 void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                                 int64_t rows, int64_t cols, int32_t dtype,
                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return xp_layernorm_bwd_side(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, accumulate, rows, cols, dtype,
+                               nullptr, 0, 0, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int xp_layernorm_bwd_side(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                                     const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                                     void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                                     int64_t rows, int64_t cols, int32_t dtype,
+                                     const float* x_side, int64_t side_S, int32_t side_M, int32_t side_stride,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   XP_REQUIRE(dgamma && dbeta, "xp_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   int rc = ln_bwd_launch("xp_layernorm_bwd", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype, 0,
-                         workspace, workspace_bytes, st);
+                         workspace, workspace_bytes, st, x_side, side_S, side_M, side_stride);
   if (rc) return rc;
   // two-level deterministic reduce of the per-block partial rows: blocks -> <=32 -> 1; dgamma/dbeta may be two
   // separate buffers, so the last level runs once per output
@@ -324,4 +345,13 @@ extern "C" int xp_layernorm_bwd_partials(const void* dy, int64_t lddy, const voi
                                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
   return ln_bwd_launch("xp_layernorm_bwd_partials", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype,
                        with_dx_colsum, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int xp_layernorm_bwd_partials_side(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                                              const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                                              void* dx, int64_t lddx, int32_t with_dx_colsum, int64_t rows, int64_t cols,
+                                              int32_t dtype, const float* x_side, int64_t side_S, int32_t side_M, int32_t side_stride,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  return ln_bwd_launch("xp_layernorm_bwd_partials_side", dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, rows, cols, dtype,
+                       with_dx_colsum, workspace, workspace_bytes, (hipStream_t)stream, x_side, side_S, side_M, side_stride);
 }

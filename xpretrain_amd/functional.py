@@ -253,13 +253,16 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
     a.mean1, a.rstd1, a.mean2, a.rstd2 = base + off["mean1"], base + off["rstd1"], base + off["mean2"], base + off["rstd2"]
     a.stats = base + off["stats"]
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    side_out = None
+    side_out = side_x2 = None
     if side is not None:
         side_out = torch.empty_like(side)
         a.side_in, a.side_out = side.data_ptr(), side_out.data_ptr()
         a.side_S, a.side_M = (plan.dims.S, plan.dims.M) if plan.dims.attn_mode == L.ATTN_PROXY else (1, 1)
+        if keep_pre:            # training pass: the x2 side rows are kept for the backward's second LayerNorm
+            side_x2 = torch.empty_like(side)
+            a.side_x2 = side_x2.data_ptr()
     L.check(L.lib().xp_encoder_layer_fwd(C.byref(a), H._stream()), "xp_encoder_layer_fwd")
-    return x3, arena, side_out
+    return x3, arena, side_out, side_x2
 
 
 # Gradient sinks (distributed.GradBucketReducer(layout_groups=...)): flat fp32 buffers -- slices of the reducer's all-reduce
@@ -286,7 +289,7 @@ def layer_grad_groups(model):
     return groups
 
 
-def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, plan):
+def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, plan, side=None, side_x2=None):
     dev = x.device
     need = ctx.needs_input_grad
     dx = torch.empty_like(x)
@@ -319,6 +322,9 @@ def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_ma
             g[name] = t
             setattr(a, name, t.data_ptr())
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    if side is not None and side_x2 is not None and os.environ.get("XPRETRAIN_LN_BWD_SIDE", "1") != "0":   # the forward's fp32 side rows of x and x2: read by the LayerNorm backward passes
+        a.side_in, a.side_x2 = side.data_ptr(), side_x2.data_ptr()
+        a.side_S, a.side_M = (plan.dims.S, plan.dims.M) if plan.dims.attn_mode == L.ATTN_PROXY else (1, 1)
     L.check(L.lib().xp_encoder_layer_bwd(C.byref(a), H._stream()), "xp_encoder_layer_bwd")
     D, Dff = plan.dims.D, plan.dims.Dff
     gw = lambda n, shape: g[n].view(shape) if n in g else None
@@ -357,9 +363,9 @@ class EncoderLayerFn(torch.autograd.Function):
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
         if LAYER_CALLS and _native_ok(x, (ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2), (Wqkv, Wo, W1, W2), pad_mask):
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
-            x3, arena, side_out = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask,
-                                                    keep_pre=training, side=side)
-            ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask)
+            x3, arena, side_out, side_x2 = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan,
+                                                             pad_mask, keep_pre=training, side=side)
+            ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, side, side_x2)
             ctx.plan = plan
             if GRAD_SINKS:          # (data-parallel runs only) the layer's parameters in the flat gradient order
                 ctx.sink_params = (ln1_w, ln1_b, wq, wk, wv, bq, bk, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2)
@@ -390,8 +396,9 @@ class EncoderLayerFn(torch.autograd.Function):
 
         if training:
             ctx.save_for_backward(x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
-                                  Wqkv, Wo, W1, W2, pad_mask)
+                                  Wqkv, Wo, W1, W2, pad_mask, side, side_x2)
         ctx.meta = (B, S, heads, size, q_scale, D, Dff)
+        ctx.lns = lns
         if side is not None:
             ctx.mark_non_differentiable(side_out)
             return x3, side_out
@@ -400,13 +407,13 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx3, _dside=None):
         if ctx.plan is not None:
-            x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask = ctx.saved_tensors
+            x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, side, side_x2 = ctx.saved_tensors
             if dx3.dtype != x.dtype or dx3.device != x.device or dx3.shape != x.shape:
                 raise TypeError(f"EncoderLayerFn.backward: incoming gradient is {dx3.dtype} {tuple(dx3.shape)} on {dx3.device}, "
                                 f"expected {x.dtype} {tuple(x.shape)} on {x.device}")
-            return _layer_bwd_native(ctx, dx3.contiguous(), x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, ctx.plan)
+            return _layer_bwd_native(ctx, dx3.contiguous(), x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, ctx.plan, side, side_x2)
         (x, ln1_w, mean1, rstd1, h1, qkv, attn_o, stats, x2, ln2_w, mean2, rstd2, h2, pre, act,
-         Wqkv, Wo, W1, W2, pad_mask) = ctx.saved_tensors
+         Wqkv, Wo, W1, W2, pad_mask, side, side_x2) = ctx.saved_tensors
         B, S, heads, size, q_scale, D, Dff = ctx.meta
         rows = x.shape[0]
         dx3 = dx3.contiguous()
@@ -427,7 +434,7 @@ class EncoderLayerFn(torch.autograd.Function):
         # out_proj's bias gradient = column sums of dx2, fc2's = column sums of dx3: both accumulated by the LayerNorm backward
         # that reads dx3 and writes dx2
         dx2, dln2_w, dln2_b, dbo, db2 = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
-                                                        dx_colsum=True, dres_colsum=True, name="ln2")
+                                                        dx_colsum=True, dres_colsum=True, name="ln2", x_side=side_x2, side=ctx.lns)
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
         dwo = _wgrad(dx2, attn_o, rows, D, D) if need[9] else None
@@ -447,7 +454,8 @@ class EncoderLayerFn(torch.autograd.Function):
             dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
         else:
             dbq = dbk = dbv = None
-        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer, name="ln1")
+        dx, dln1_w, dln1_b = H.layernorm_bwd(dh1, x, ln1_w, mean1, rstd1, rows, D, dres=dx2, defer=defer, name="ln1", x_side=side,
+                                             side=ctx.lns)
         defer.flush()
         keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
         return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),
@@ -551,7 +559,8 @@ class LayerNormFn(torch.autograd.Function):
         rows, D = x.shape
         y_side = torch.empty_like(x_side) if want_y_side else None
         y, mean, rstd = H.layernorm_fwd(x, gamma.detach(), beta.detach(), rows, D, x_side=x_side, y_side=y_side, side=side)
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.save_for_backward(x, gamma, mean, rstd, x_side)
+        ctx.side = side
         if want_y_side:
             ctx.mark_non_differentiable(y_side)
             return y, y_side
@@ -559,9 +568,9 @@ class LayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dys=None):
-        x, gamma, mean, rstd = ctx.saved_tensors
+        x, gamma, mean, rstd, x_side = ctx.saved_tensors
         rows, D = x.shape
-        dx, dg, db = H.layernorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd, rows, D)
+        dx, dg, db = H.layernorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd, rows, D, x_side=x_side, side=ctx.side)
         return dx, dg, db, None, None, None
 
 

@@ -230,18 +230,25 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, dres=None, dx=None, lddx=None,
                   dgamma=None, dbeta=None, accumulate=False, defer: "DeferredReduce" = None, dx_colsum=False, dres_colsum=False,
-                  name="ln"):
-    """Returns (dx, dgamma, dbeta) -- plus colsum(dx) when ``dx_colsum``, plus colsum(dres) when ``dres_colsum`` (deferred mode only)."""
+                  name="ln", x_side=None, side=None):
+    """Returns (dx, dgamma, dbeta) -- plus colsum(dx) when ``dx_colsum``, plus colsum(dres) when ``dres_colsum`` (deferred mode only).
+    ``x_side`` / ``side = (S, M, stride)``: the fp32 side rows of x the forward normalised (layernorm_fwd)."""
     _chk(dy, "dy"); _chk(x, "x", dy.dtype)
+    S, M, stride = side if x_side is not None else (0, 0, 0)
+    if x_side is not None:
+        _chk(x_side, "x_side", torch.float32)
+        if not x_side.is_contiguous() or x_side.numel() < ((rows - 1) // S * stride + min(M, S)) * cols:
+            raise ValueError("layernorm_bwd: x_side is too small or not contiguous")
     dx = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device) if dx is None else dx
     dgamma = torch.empty(cols, dtype=torch.float32, device=dy.device) if dgamma is None else dgamma
     dbeta = torch.empty(cols, dtype=torch.float32, device=dy.device) if dbeta is None else dbeta
     nb = L.lib().xp_layernorm_bwd_workspace_bytes(rows, cols)
     if defer is not None:     # parameter-gradient partial rows stay in their own slot until defer.flush()
         ws = defer.slot(nb, name)
-        L.check(L.lib().xp_layernorm_bwd_partials(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
-                                                  _p(dres), cols, _p(dx), lddx or cols, 2 if dres_colsum else int(dx_colsum), rows, cols,
-                                                  _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd_partials")
+        L.check(L.lib().xp_layernorm_bwd_partials_side(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
+                                                       _p(dres), cols, _p(dx), lddx or cols, 2 if dres_colsum else int(dx_colsum),
+                                                       rows, cols, _dt(dy), _p(x_side), S, M, stride, _p(ws), ws.numel(), _stream()),
+                "xp_layernorm_bwd_partials_side")
         nrows = L.lib().xp_layernorm_bwd_partial_rows(rows)
         if dres_colsum and not (dx_colsum and dres is not None):
             raise ValueError("layernorm_bwd: dres_colsum needs dx_colsum and dres")
@@ -260,9 +267,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, ldx=None, lddy=None, 
     if dx_colsum:
         raise ValueError("layernorm_bwd: dx_colsum needs a DeferredReduce")
     ws = workspace(nb, dy.device, "ln")
-    L.check(L.lib().xp_layernorm_bwd(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
-                                     _p(dres), cols, _p(dx), lddx or cols, _p(dgamma), _p(dbeta), int(accumulate),
-                                     rows, cols, _dt(dy), _p(ws), ws.numel(), _stream()), "xp_layernorm_bwd")
+    L.check(L.lib().xp_layernorm_bwd_side(_p(dy), lddy or cols, _p(x), ldx or cols, _p(gamma), _p(mean), _p(rstd),
+                                          _p(dres), cols, _p(dx), lddx or cols, _p(dgamma), _p(dbeta), int(accumulate),
+                                          rows, cols, _dt(dy), _p(x_side), S, M, stride, _p(ws), ws.numel(), _stream()),
+            "xp_layernorm_bwd_side")
     return dx, dgamma, dbeta
 
 
