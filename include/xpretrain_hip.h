@@ -77,10 +77,12 @@ typedef struct XpGemmDesc {
    * Only where xp_gemm_colsum_rows() > 0 (large bf16 problems, EPI_NONE / EPI_GELU_BWD); finish with
    * xp_reduce_rows_batch. */
   float* colsum_partials;
-  /* 0: library default (256-row tiles where the 256-wide family runs); 224: prefer 224-row tiles where they fill the last round
-   * of CUs better.  On MI355X the GEMMs run against the power limit: at 18848 rows 224-row tiles finish a forward-only pass 3.8 %
-   * sooner but cost 0.7 % more time per training step (more N-side operand traffic per FLOP), so latency-first callers (inference
-   * forward: retrieval, tasks/run_video_retrieval.py:123-203) ask for 224 and the training step keeps 256. */
+  /* Which kernels of the 256-wide family serve the call (no effect elsewhere).  0: library default = what is fastest INSIDE the
+   * training step: 256-row tiles, LDS-staged epilogue (csrc/gemm256s.hip).  224: latency-first -- the direct-epilogue / persistent
+   * kernels (csrc/gemm256.hip) with 224-row tiles where they fill the last round of CUs better; a forward-only pass is 2-4 % faster
+   * with them, so the inference forward (retrieval, tasks/run_video_retrieval.py:123-203) asks for it.  256: those kernels at 256-row
+   * tiles (tests, A/B).  On MI355X the GEMMs run against the power limit, and the choice was made by timing whole training steps
+   * of both kernel sets on one box: isolated launches rank them the other way round. */
   int32_t tile_rows_hint;
   int32_t side_M;
   /* optional, EPI_BIAS_RESID: fp32 "side rows" of the residual stream.  Output rows m with m % side_S < side_M (the video tower's

@@ -133,46 +133,60 @@ def force_gemm256(monkeypatch):
     monkeypatch.setenv("XPRETRAIN_GEMM256_SPLITK", "1")
 
 
+# tile_rows_hint 0: the library default for training-shaped calls (staged-epilogue kernels, gemm256s.hip); 256: the direct-epilogue
+# kernels of gemm256.hip at the same tile height (224: those kernels with 224-row tiles where the cost model picks them, below)
+HINTS = [0, 256]
+
+
+@pytest.mark.parametrize("hint", HINTS)
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1280, 512, 768), (1100, 768, 256), (300, 260, 96), (2356, 768, 3072)])
-def test_gemm256_nt(force_gemm256, dtype, M, N, K):
+def test_gemm256_nt(force_gemm256, dtype, M, N, K, hint):
     from xpretrain_amd import hip_ops as H
     torch.manual_seed(M + N + K)
     A, B = _mk((M, K), dtype), _mk((N, K), dtype)
-    C = H.gemm(A, B, M, N, K)
+    C = H.gemm(A, B, M, N, K, tile_rows_hint=hint)
     ref = A.double() @ B.double().t()
     assert report(f"gemm256_nt {dtype} {M}x{N}x{K}", C, ref, TOL[dtype]) <= TOL[dtype]
 
 
+@pytest.mark.parametrize("hint", HINTS)
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1280, 768, 2304), (520, 256, 72), (2356, 3072, 768)])
-def test_gemm256_nn(force_gemm256, dtype, M, N, K):
+def test_gemm256_nn(force_gemm256, dtype, M, N, K, hint):
     from xpretrain_amd import hip_ops as H
     torch.manual_seed(1)
     A, W = _mk((M, K), dtype), _mk((K, N), dtype)
-    C = H.gemm(A, W, M, N, K, b_kstrided=True)
+    C = H.gemm(A, W, M, N, K, b_kstrided=True, tile_rows_hint=hint)
     ref = A.double() @ W.double()
     assert report(f"gemm256_nn {dtype} {M}x{N}x{K}", C, ref, TOL[dtype]) <= TOL[dtype]
 
 
+@pytest.mark.parametrize("hint", HINTS)
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,split", [(768, 1024, 1000, 1), (256, 512, 77, 1), (768, 768, 4000, 8)])
-def test_gemm256_tn(force_gemm256, dtype, M, N, K, split):
+def test_gemm256_tn(force_gemm256, dtype, M, N, K, split, hint):
     from xpretrain_amd import hip_ops as H
     torch.manual_seed(2)
     Y, X = _mk((K, M), dtype), _mk((K, N), dtype)
     if split == 1:
-        C = H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, out_dtype=torch.float32)
+        C = H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, out_dtype=torch.float32, tile_rows_hint=hint)
     else:
-        C = H.splitk_reduce(H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, split_k=split), torch.empty(M, N, device="cuda"))
+        C = H.splitk_reduce(H.gemm(Y, X, M, N, K, a_kstrided=True, b_kstrided=True, split_k=split, tile_rows_hint=hint),
+                            torch.empty(M, N, device="cuda"))
     ref = Y.double().t() @ X.double()
     assert report(f"gemm256_tn {dtype} {M}x{N}x{K} split{split}", C, ref, 2e-5) <= 2e-5
 
 
+@pytest.mark.parametrize("hint", HINTS)
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm256_epilogues(force_gemm256, dtype):
-    from xpretrain_amd import hip_ops as H
+def test_gemm256_epilogues(force_gemm256, dtype, hint):
+    import functools
+    from xpretrain_amd import hip_ops as H0
     from xpretrain_amd import _lib as L
+
+    class H:                                          # every call of this test with the tile hint under test
+        gemm = staticmethod(functools.partial(H0.gemm, tile_rows_hint=hint))
     torch.manual_seed(3)
     M, N, K = 1100, 512, 192
     A, B = _mk((M, K), dtype, 0.5), _mk((N, K), dtype, 0.2)
@@ -195,8 +209,9 @@ def test_gemm256_epilogues(force_gemm256, dtype):
     assert report(f"g256 epi_gelu_bwd {dtype}", C, acc * (s * (1 + 1.702 * x * (1 - s))), tol) <= tol
 
 
+@pytest.mark.parametrize("hint", HINTS)
 @pytest.mark.parametrize("epi", ["none", "gelu_bwd"])
-def test_gemm_fused_colsum(epi):
+def test_gemm_fused_colsum(epi, hint):
     """Column sums of the finished outputs from the GEMM epilogue (the bias gradient of the producing Linear), M not a
     multiple of the tile (rows >= M must not contribute), vs fp64."""
     from xpretrain_amd import hip_ops as H
@@ -209,6 +224,7 @@ def test_gemm_fused_colsum(epi):
     pre = torch.randn(M, N, device="cuda").to(bf)
     defer = H.DeferredReduce(dY.device)
     kw = dict(epilogue=L.EPI_GELU_BWD, resid=pre) if epi == "gelu_bwd" else {}
+    kw["tile_rows_hint"] = hint
     out, cs = H.gemm(dY, W, M, N, K, b_kstrided=True, colsum_defer=defer, **kw)
     assert len(defer.segs) == 1 and defer.segs[0].nrows == 2 * ((M + 255) // 256)      # the fused path was taken (256-row tiles)
     defer.flush()
@@ -219,7 +235,8 @@ def test_gemm_fused_colsum(epi):
     assert report(f"fused colsum {epi} out", out, ref, 6e-3) <= 6e-3
     assert report(f"fused colsum {epi}", cs, ref.sum(0), 2e-3) <= 2e-3
     # small problem: the library declines the fusion, the wrapper falls back to a separate pass with the same result
-    out2, cs2 = H.gemm(dY[:300].contiguous(), W, 300, N, K, b_kstrided=True, colsum_defer=defer, **({} if epi == "none" else dict(epilogue=L.EPI_GELU_BWD, resid=pre[:300].contiguous())))
+    out2, cs2 = H.gemm(dY[:300].contiguous(), W, 300, N, K, b_kstrided=True, colsum_defer=defer, tile_rows_hint=hint,
+                       **({} if epi == "none" else dict(epilogue=L.EPI_GELU_BWD, resid=pre[:300].contiguous())))
     defer.flush()
     assert report(f"fallback colsum {epi}", cs2, out2.double().sum(0), 1e-5) <= 1e-5
 
@@ -311,11 +328,15 @@ def test_gemm256_persistent_tile_loop(M, N, K):
     """More tiles than CUs in the forward orientation: one workgroup per CU walks several tiles, the next tile's first half-tiles
     are prefetched under the current tile's stores (gemm256_persist_kernel).  Every epilogue it serves, both tile heights, a ragged
     last tile, and bit-equality with the one-tile-per-workgroup kernel (same arithmetic, different schedule)."""
+    import functools
     import os
     import subprocess
     import sys
-    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import hip_ops as H0
     from xpretrain_amd import _lib as L
+
+    class H:                                          # the direct-epilogue kernels (the persistent loop is theirs) at 256-row tiles
+        gemm = staticmethod(functools.partial(H0.gemm, tile_rows_hint=256))
     torch.manual_seed(M + N)
     bf = torch.bfloat16
     A, B = _mk((M, K), bf, 0.5), _mk((N, K), bf, 0.2)
@@ -324,7 +345,8 @@ def test_gemm256_persistent_tile_loop(M, N, K):
     tol = TOL[bf]
     C0 = H.gemm(A, B, M, N, K)
     assert report("persist none", C0, acc, tol) <= tol
-    assert torch.equal(H.gemm(A, B, M, N, K, tile_rows_hint=224), C0)       # 224-row tiles: same k order, bit-identical
+    assert torch.equal(H0.gemm(A, B, M, N, K, tile_rows_hint=224), C0)      # 224-row tiles: same k order, bit-identical
+    assert report("staged kernels vs persistent", H0.gemm(A, B, M, N, K), C0, 1e-6) <= 1e-6     # (default family: same k order too)
     C1 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)
     assert report("persist bias", C1, acc + bias.double(), tol) <= tol
     C2 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_QSCALE, bias=bias, scale=0.125, scale_cols=256)
@@ -345,8 +367,8 @@ def test_gemm256_persistent_tile_loop(M, N, K):
             "from xpretrain_amd import hip_ops as H, _lib as L\n"
             "d = torch.load('/tmp/xp_persist_case.pt'); A, B, bias = d['A'].cuda(), d['B'].cuda(), d['bias'].cuda()\n"
             "M, K = A.shape; N = B.shape[0]\n"
-            "C1 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias)\n"
-            "C3 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias)\n"
+            "C1 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS, bias=bias, tile_rows_hint=256)\n"
+            "C3 = H.gemm(A, B, M, N, K, epilogue=L.EPI_BIAS_GELU, bias=bias, tile_rows_hint=256)\n"
             "assert torch.equal(C1.cpu(), d['C1']) and torch.equal(C3.cpu(), d['C3'])\nprint('same')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, XPRETRAIN_GEMM256_PERSIST="0"),
@@ -354,7 +376,8 @@ def test_gemm256_persistent_tile_loop(M, N, K):
     assert out.returncode == 0 and "same" in out.stdout, out.stderr[-1500:]
 
 
-@pytest.mark.parametrize("M,N,K,S,Ms,hint", [(18848, 768, 192, 2356, 4, 0), (18848, 768, 192, 2356, 4, 224), (4712, 768, 3072, 2356, 4, 0),
+@pytest.mark.parametrize("M,N,K,S,Ms,hint", [(18848, 768, 192, 2356, 4, 0), (18848, 768, 192, 2356, 4, 224), (18848, 768, 192, 2356, 4, 256),
+                                             (4712, 768, 3072, 2356, 4, 0), (4712, 768, 3072, 2356, 4, 256),
                                              (200, 256, 128, 50, 3, 0), (40, 64, 64, 10, 4, 0)])
 def test_resid_epilogue_with_fp32_side_rows(M, N, K, S, Ms, hint):
     """EPI_BIAS_RESID with the fp32 side rows of the residual stream (XpGemmDesc::resid_side / out_side): rows m with m % S < Ms take

@@ -10,7 +10,7 @@ run() {   # name, counters...
   rm -rf /tmp/pmc_$NAME
   ( cd $REPO && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$NAME -o $NAME -- python tools/gemm256_probe.py 4 ) > $OUT/${TAG}_pmc_${NAME}.log 2>&1
   local F=$(find /tmp/pmc_$NAME -name "*counter_collection.csv" | head -1)
-  python3 $REPO/tools/pmc_summarize.py $F $OUT/${TAG}_pmc_${NAME}_gemm256.csv gemm256_ cast_kernel > $OUT/${TAG}_pmc_${NAME}.txt
+  python3 $REPO/tools/pmc_summarize.py $F $OUT/${TAG}_pmc_${NAME}_gemm256.csv gemm256 cast_kernel > $OUT/${TAG}_pmc_${NAME}.txt
   tail -n 40 $OUT/${TAG}_pmc_${NAME}.txt
 }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS

@@ -594,6 +594,10 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
              split, (long long)d->K, zsplits);
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   hipStream_t st = (hipStream_t)stream;
+  if (xp_gemm256s_selected(d) && xp_gemm256_wanted(d, split) && xp_gemm256s_try(d, kp, st)) {   // staged-epilogue kernels of the family
+    XP_CHECK_LAUNCH("xp_gemm(256s)");
+    return XP_OK;
+  }
   if (xp_gemm256_try(d, kp, st)) {     // large dense problems: 256x256 ping-pong family
     XP_CHECK_LAUNCH("xp_gemm(256)");
     return XP_OK;

@@ -1,0 +1,381 @@
+// 256x256-tile MFMA GEMM, 8-wave ping-pong main loop with an LDS-STAGED epilogue: the round-2 form of the family in gemm256.hip,
+// kept as a second set of kernels because it is the faster one INSIDE the training step (round 3, same box, same step:
+// profiles/r03w_*): gemm256.hip's direct epilogue / N-side row permutation / persistent tile loop win 2-6 % in isolated launches
+// and in the forward-only pass, but in the power-limited step the dX GEMMs ran 4.8 % and the forward GEMMs 2.7 %
+// slower than these kernels.  Selection: xp_gemm256s_selected (XPRETRAIN_GEMM256_STAGED, a mask over the operand layouts);
+// latency-first calls (XpGemmDesc::tile_rows_hint == 224) always take gemm256.hip.
+//
+//   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 accumulators (128 registers)
+//   k-tile     64 bf16 of k = four 16 KiB half-tiles, ring of 8 slots = 128 KiB LDS, two phases of 32 MFMAs per k-tile, the wm==1
+//              waves one barrier behind the wm==0 waves (see gemm256.hip for the schedule; this file shares its LDS images)
+//   epilogue   wave-private LDS staging (rounds of 32 rows x 64 cols fp32), row-major read-back, shared fused epilogue
+//              (gemm_common.h::FastEpi, incl. the fp32 side rows and the fused column sums)
+#include "common.h"
+#include "gemm_common.h"
+#include <stdlib.h>
+#include <mutex>
+
+namespace {
+
+using namespace xpgemm;
+
+typedef bf16_t T;
+constexpr int TM = 256, TN = 256, SKB = 128, KE = 64;   // SKB: bytes of k per k-tile
+constexpr int NTH = 512, NWAVES = 8;
+constexpr int WAVES_N = 4, MT = 8, NT = 4;               // wave tile 128 x 64
+constexpr int HALF_ROWS = 128, HALF_BYTES = HALF_ROWS * SKB, NSLOT = 8, LDS_BYTES = NSLOT * HALF_BYTES;
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+// DMA of one operand's half-tiles.  SUB = rows of one wave in a half (64 on the M side, 32 on the N side):
+// local row r of half h is tile row (r / SUB) * 2 * SUB + h * SUB + r % SUB.
+template <bool KS, int SUB>
+struct HalfStager {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[2][2];     // [half][pass]
+  unsigned step;
+  unsigned lds_off[2];
+
+  static __device__ __forceinline__ int tile_row(int r, int h) { return (r / SUB) * (2 * SUB) + h * SUB + (r % SUB); }
+
+  __device__ __forceinline__ void init(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t kend, int64_t kbeg,
+                                       int lane, int wave) {
+    const int64_t bytes = (KS ? kend : rows) * ld * 2;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (unsigned)bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pass = j * NWAVES + wave;        // 16 passes of 1 KiB per half-tile
+      lds_off[j] = pass * 1024;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t off;
+        if constexpr (!KS) {
+          const int row = pass * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ swz128(row);
+          off = ((row0 + tile_row(row, h)) * ld + kbeg) * 2 + c * 16;
+        } else {
+          const int kr = pass * 4 + (lane >> 4), c16 = lane & 15;
+          const int src = (((c16 >> 1) ^ ks_f(kr)) << 1) | (c16 & 1);
+          off = ((kbeg + kr) * ld + row0 + tile_row(src * 8, h)) * 2;
+        }
+        voff[h][j] = off >= bytes ? 0xFFFFFFF0u : (unsigned)off;
+      }
+    }
+    step = (unsigned)((KS ? (int64_t)KE * ld : (int64_t)KE) * 2);
+  }
+  __device__ __forceinline__ void issue(char* slot, int h, int kt) const {
+    lds_char* t3 = (lds_char*)slot;
+    const unsigned adv = (unsigned)kt * step;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      unsigned o = voff[h][j] + adv;
+      if (o < voff[h][j]) o = 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, t3 + lds_off[j], 16, o, 0, 0, 0);
+    }
+  }
+};
+
+// fragment of local 16-row sub-tile `ot` (0..7) of a half-tile for the 32-element k sub-step `ks` (0..1)
+template <bool KS>
+__device__ __forceinline__ bf16x8 frag(const char* tile, int ot, int ks, int lane) {
+  constexpr int RB = HALF_ROWS * 2;
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (!KS) {
+    return *reinterpret_cast<const bf16x8*>(tile + tile128_off(ot * 16 + i, ks * 4 + g));
+  } else {
+    const int f = (i >> 2) | ((g & 1) << 2);
+    const int kr = ks * 32 + g * 8 + (i >> 2);
+    const char* p = tile + kr * RB + ((ot ^ f) << 5) + ((i & 3) << 3);
+    // asm reads (no compiler-inserted vmcnt(0) beside the DMA ring); consumed after XP_PHASE_MMA's s_waitcnt lgkmcnt(0)
+    i16x4 lo = lds_read_tr16_async<0>(p);
+    i16x4 hi = lds_read_tr16_async<4 * RB>(p);
+    typedef __attribute__((ext_vector_type(8))) short i16x8;
+    i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(NTH, 2) void gemm256s_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg, p.xcd_remap);
+  int tm, tn;
+  tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
+
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int nk = (int)((kend - kbeg + KE - 1) / KE);       // >= 2 (launcher)
+
+  HalfStager<AKS, 64> ga;
+  HalfStager<BKS, 32> gb;
+  ga.init(reinterpret_cast<const T*>(p.A), p.lda, m0, p.M, kend, kbeg, lane, wave);
+  gb.init(reinterpret_cast<const T*>(p.B), p.ldb, n0, p.N, kend, kbeg, lane, wave);
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bool trace = p.dbg != nullptr && (int)blockIdx.x == nwg / 2 && blockIdx.z == 0 && wave == 0;
+  unsigned long long* tr = p.dbg;
+  if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
+
+  // Half-tiles in consumption order: j = 4*kt + w with w 0: A0(kt), 1: B1(kt), 2: A1(kt), 3: B0(kt+1); slot j % 8.
+  // B0 of k-tile 0 ("j = -1") uses slot 7.
+  auto slot = [&](int kt, int w) -> char* { return smem + (((kt & 1) << 2) + w) * HALF_BYTES; };
+
+  // prologue: B0(0) and half-tiles 0..3 in flight; B0(0), A0(0), B1(0) landed everywhere before the first phase
+  gb.issue(slot(1, 3), 0, 0);
+  ga.issue(slot(0, 0), 0, 0); gb.issue(slot(0, 1), 1, 0); ga.issue(slot(0, 2), 1, 0); gb.issue(slot(0, 3), 0, 1);
+  wait_vmcnt<4>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();       // the wm==1 group runs one barrier behind
+
+  bf16x8 fa[2][4], fb[2][2][2], fbn[2][2];          // fa[ks][mt] (current A half), fb[hB][ks][nt], fbn: next k-tile's B0
+
+#define XP_PHASE_MMA(HA)                                                                              \
+  do {                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int hb = 0; hb < 2; ++hb)                                                  \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
+          _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                            \
+            acc[hb * 2 + nt][(HA) * 4 + mt] = mma16(fb[hb][ks][nt], fa[ks][mt], acc[hb * 2 + nt][(HA) * 4 + mt]); \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_barrier();                                                                     \
+  } while (0)
+#define XP_READ_A(TILE)                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) fa[ks][mt] = frag<AKS>(TILE, wm * 4 + mt, ks, lane)
+#define XP_READ_B(DST, TILE)                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) DST[ks][nt] = frag<BKS>(TILE, wn * 2 + nt, ks, lane)
+
+  XP_READ_B(fbn, slot(1, 3));                       // B0 of k-tile 0
+
+  // One k-tile = 2 phases of 32 MFMAs: A0 x (B0, B1), then A1 x (B0, B1); 12 fragment reads and 2 half-tile DMAs each.
+  // TAIL 0: steady state, 1: k-tile nk-2, 2: k-tile nk-1 (fewer half-tiles left to issue / await).
+  auto ktile = [&](int t, auto tail_c) {
+    constexpr int TAIL = decltype(tail_c)::value;
+    // ---- phase 0: A0 x (B0, B1); issues A0, B1 of k-tile t+1; afterwards A1(t) and B0(t+1) have landed ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) fb[0][ks][nt] = fbn[ks][nt];
+    XP_READ_B(fb[1], slot(t, 1));
+    __builtin_amdgcn_sched_barrier(0);
+    XP_READ_A(slot(t, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAIL <= 1) { ga.issue(slot(t + 1, 0), 0, t + 1); gb.issue(slot(t + 1, 1), 1, t + 1); }
+    wait_vmcnt<(TAIL <= 1 ? 4 : 0)>();
+    XP_PHASE_MMA(0);
+    // ---- phase 1: A1 x (B0, B1); issues A1(t+1), B0(t+2); afterwards A0, B1 of k-tile t+1 have landed ----
+    if constexpr (TAIL <= 1) { XP_READ_B(fbn, slot(t, 3)); }
+    __builtin_amdgcn_sched_barrier(0);
+    XP_READ_A(slot(t, 2));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAIL <= 1) ga.issue(slot(t + 1, 2), 1, t + 1);
+    if constexpr (TAIL == 0) gb.issue(slot(t + 1, 3), 0, t + 2);
+    wait_vmcnt<(TAIL == 0 ? 4 : (TAIL == 1 ? 2 : 0))>();
+    XP_PHASE_MMA(1);
+  };
+  for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
+  ktile(nk - 2, std::integral_constant<int, 1>{});
+  ktile(nk - 1, std::integral_constant<int, 2>{});
+#undef XP_PHASE_MMA
+#undef XP_READ_A
+#undef XP_READ_B
+  if (wm == 0) __builtin_amdgcn_s_barrier();       // re-align the two wave groups
+  __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring -> LDS is free for the epilogue
+  if (trace && lane == 0) tr[2] = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue: wave-private staging, MT/2 rounds of 32 rows x 64 columns fp32 ------------------------------------
+  constexpr int CW = NT * 16;
+  char* stg = smem + wave * (32 * CW * 4);
+  const int i16 = lane & 15, g = lane >> 4;
+  float* Cf = reinterpret_cast<float*>(p.C);
+  T* Ct = reinterpret_cast<T*>(p.C);
+  if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
+  auto stage_round = [&](int q) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = h * 16 + i16;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(stg + row * (CW * 4) + (((nt * 4 + g) ^ (row & 7)) << 4)) = acc[nt][q * 2 + h];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c, auto cs_c) {
+    constexpr int EPI = decltype(epi_c)::value;
+    constexpr bool F32 = decltype(f32_c)::value;
+    constexpr bool COLSUM = decltype(cs_c)::value;
+    f32x8 cs = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int c = lane & 7, r8 = lane >> 3;           // 8 columns per lane: 8 lanes per row, 8 rows per pass
+    const FastEpi<T, EPI, F32> fe(p, F32 ? (void*)Cf : (void*)Ct, n0 + wn * CW + c * 8);
+    const unsigned mrow = (unsigned)(m0 + wm * (MT * 16)) + r8;
+    Raw8<T> pre[2][4];
+    if constexpr (EpiTraits<EPI>::pre) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) pre[0][pass] = fe.load_pre(mrow + pass * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < MT / 2; ++q) {
+      if constexpr (EpiTraits<EPI>::pre) {
+        if (q + 1 < MT / 2) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) pre[(q + 1) & 1][pass] = fe.load_pre(mrow + (q + 1) * 32 + pass * 8);
+        }
+      }
+      stage_round(q);
+      f32x8 v[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + r8;
+        v[pass].lo = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c) ^ (row & 7)) << 4));
+        v[pass].hi = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c + 1) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const f32x8 o = fe.finish(v[pass], pre[q & 1][pass], mrow + q * 32 + pass * 8);
+        if constexpr (COLSUM) {
+          if (mrow + q * 32 + pass * 8 < (unsigned)p.M) { cs.lo += o.lo; cs.hi += o.hi; }     // rows >= M are not outputs
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (COLSUM) {
+      // the 8 lanes r8 = 0..7 of a column octet hold different rows: butterfly over lane bits 3..5, then lane r8 == 0
+      // writes this wave's 128-row column sums (one partial row per (tile row, wm))
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs.lo[e] += __shfl_xor(cs.lo[e], o, 64); cs.hi[e] += __shfl_xor(cs.hi[e], o, 64); }
+      const int64_t n = n0 + wn * CW + c * 8;
+      if (r8 == 0 && n < p.N) {
+        float* dst = p.colsum + ((int64_t)tm * 2 + wm) * p.N + n;
+        store4(dst, cs.lo); store4(dst + 4, cs.hi);
+      }
+    }
+  });
+  if (fast) {
+  } else if (p.wide) {                              // 8 columns per lane: 8 lanes per row, 8 rows per pass
+    const int c = lane & 7, r8 = lane >> 3;
+    const int64_t n = n0 + wn * CW + c * 8;
+    const bool ncol_ok = n < p.N;
+    const EpiLane8 el(p, ncol_ok ? n : 0);
+#pragma unroll
+    for (int q = 0; q < MT / 2; ++q) {
+      stage_round(q);
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + r8;
+        const int64_t m = m0 + wm * (MT * 16) + q * 32 + row;
+        f32x8 v;
+        v.lo = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c) ^ (row & 7)) << 4));
+        v.hi = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + (((2 * c + 1) ^ (row & 7)) << 4));
+        if (ncol_ok && m < p.M) epi_row8<T>(p, el, v, m, n, Cf, Ct);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    const int c = lane & 15, r4 = lane >> 4;
+    const int64_t n = n0 + wn * CW + c * 4;
+    const bool ncol_ok = n < p.N;
+    const EpiLane el(p, ncol_ok ? n : 0);
+#pragma unroll
+    for (int q = 0; q < MT / 2; ++q) {
+      stage_round(q);
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 4 + r4;
+        const int64_t m = m0 + wm * (MT * 16) + q * 32 + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * (CW * 4) + ((c ^ (row & 7)) << 4));
+        if (ncol_ok && m < p.M) epi_row<T>(p, el, v, m, n, Cf, Ct);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
+}
+
+template <bool AKS, bool BKS>
+void launch_one(const KParams& kp, dim3 grid, hipStream_t st) {
+  auto kern = gemm256s_kernel<AKS, BKS>;
+  static std::once_flag configured;            // (forward thread and autograd thread may both arrive first)
+  std::call_once(configured, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  });
+  kern<<<grid, NTH, LDS_BYTES, st>>>(kp);
+}
+
+// explicit instantiations (hipcc otherwise drops the host stubs of the k-strided variants)
+template __global__ void gemm256s_kernel<false, false>(KParams);
+template __global__ void gemm256s_kernel<false, true>(KParams);
+template __global__ void gemm256s_kernel<true, true>(KParams);
+template __global__ void gemm256s_kernel<true, false>(KParams);
+
+}  // namespace
+
+// preconditions of the family that do not depend on split_k
+bool xp_gemm256s_legal(const XpGemmDesc* d) {
+  if (d->in_dtype != XP_BF16 || d->a_grp != 0) return false;
+  const int64_t a_rows = d->a_kstrided ? d->K : d->M, b_rows = d->b_kstrided ? d->K : d->N;
+  if (!d->a_kstrided && (d->K % KE != 0 || d->lda != d->K)) return false;
+  if (!d->b_kstrided && (d->K % KE != 0 || d->ldb != d->K)) return false;
+  if (d->a_kstrided && (d->M % TM != 0 || d->lda != d->M)) return false;
+  if (d->b_kstrided && (d->N % TN != 0 || d->ldb != d->N)) return false;
+  const int64_t lim = (int64_t)0xFFFFFFF0u - 512 * 1024 * 1024;
+  if ((a_rows + TM) * d->lda * 2 >= lim || (b_rows + TN) * d->ldb * 2 >= lim) return false;
+  return true;
+}
+
+// XPRETRAIN_GEMM256_STAGED: mask of the operand layouts that take this family -- 1: NT (forward), 2: B k-strided (dX),
+// 4: both k-strided (dW).  Default from the in-step A/B (profiles/r03w_*).
+bool xp_gemm256s_selected(const XpGemmDesc* d) {
+  static const int mask = getenv("XPRETRAIN_GEMM256_STAGED") ? atoi(getenv("XPRETRAIN_GEMM256_STAGED")) : XP_GEMM256_STAGED_DEFAULT;
+  static const bool forced_height = getenv("XPRETRAIN_GEMM256_MT1") || getenv("XPRETRAIN_GEMM256_MT1_NS");   // (tile-height experiments)
+  if (forced_height) return false;
+  if (d->tile_rows_hint != 0) return false;          // 224: latency-first, 256: the direct-epilogue kernels at 256 rows (tests, A/B)
+  return (mask & (d->a_kstrided ? 4 : d->b_kstrided ? 2 : 1)) != 0;
+}
+
+// XPRETRAIN_GEMM256: 0 = never, 1 = when it fills at least half the CUs (default), 2 = whenever legal.
+bool xp_gemm256s_wanted(const XpGemmDesc* d, int split) {
+  const char* env = getenv("XPRETRAIN_GEMM256");
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || !xp_gemm256s_legal(d)) return false;
+  if (mode == 1 && cdiv(d->M, TM) * cdiv(d->N, TN) * split < 128) return false;
+  return true;
+}
+
+bool xp_gemm256s_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st) {
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  if (!xp_gemm256s_wanted(d, split)) return false;
+  xpgemm::KParams kp = kp_base;
+  kp.k_per_split = cdiv(cdiv(d->K, split), KE) * KE;
+  if (split > 1 && cdiv(d->K, kp.k_per_split) != split) return false;
+  const int64_t k_last = d->K - (int64_t)(split - 1) * kp.k_per_split;
+  if (cdiv(k_last, KE) < 2) return false;                                         // the pipeline needs >= 2 k-tiles
+  kp.tiles_m = (int)cdiv(d->M, TM); kp.tiles_n = (int)cdiv(d->N, TN);
+  kp.group_n = kp.tiles_n;
+  dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
+  if (!d->a_kstrided && !d->b_kstrided)      launch_one<false, false>(kp, grid, st);
+  else if (!d->a_kstrided && d->b_kstrided)  launch_one<false, true>(kp, grid, st);
+  else if (d->a_kstrided && d->b_kstrided)   launch_one<true, true>(kp, grid, st);
+  else                                       launch_one<true, false>(kp, grid, st);
+  return true;
+}

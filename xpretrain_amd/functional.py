@@ -374,6 +374,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 ctx.sink_params, ctx.sink_key = (), None
             if side is not None:
                 ctx.mark_non_differentiable(side_out)
+                ctx.set_materialize_grads(False)       # no zero-filled "gradient" of the side rows in the backward
                 return x3, side_out
             return x3
         ctx.plan = None
@@ -401,11 +402,14 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.lns = lns
         if side is not None:
             ctx.mark_non_differentiable(side_out)
+            ctx.set_materialize_grads(False)
             return x3, side_out
         return x3
 
     @staticmethod
     def backward(ctx, dx3, _dside=None):
+        if dx3 is None:             # (set_materialize_grads(False): the layer output did not reach the loss)
+            return (None,) * 24
         if ctx.plan is not None:
             x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, side, side_x2 = ctx.saved_tensors
             if dx3.dtype != x.dtype or dx3.device != x.device or dx3.shape != x.shape:
@@ -563,11 +567,14 @@ class LayerNormFn(torch.autograd.Function):
         ctx.side = side
         if want_y_side:
             ctx.mark_non_differentiable(y_side)
+            ctx.set_materialize_grads(False)
             return y, y_side
         return y
 
     @staticmethod
     def backward(ctx, dy, _dys=None):
+        if dy is None:
+            return (None,) * 6
         x, gamma, mean, rstd, x_side = ctx.saved_tensors
         rows, D = x.shape
         dx, dg, db = H.layernorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd, rows, D, x_side=x_side, side=ctx.side)
