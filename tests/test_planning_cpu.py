@@ -48,6 +48,7 @@ def test_fused_colsum_availability():
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_GELU_BWD, **big))) == 2 * 74      # 74 tiles of 256 rows (default height)
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, **big))) == 2 * 74
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, hint=224, **big))) == 2 * 85
+    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, hint=256, **big))) == 2 * 74   # both kernel sets: one row per wave row
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(256, 2048, 512, epi=L.EPI_GELU_BWD, **big))) == 0          # text tower: 128 family
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_BIAS, **big))) == 0            # other epilogue
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, a_ks=False, b_ks=True, out=L.XP_F32))) == 0
@@ -63,7 +64,8 @@ def test_tile_height_planning():
     act = dict(a_ks=False, b_ks=False, out=L.XP_BF16)
     for N in (768, 2304, 3072):
         assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, hint=224, **act))) == 224
-        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, **act))) == 256
+        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, **act))) == 256             # default: the staged-epilogue kernels
+        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, hint=256, **act))) == 256   # the direct-epilogue kernels at 256 rows
     assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, 768, 3072, a_ks=False, b_ks=True, out=L.XP_BF16, hint=224))) == 224
     assert lib.xp_gemm_tile_rows(C.byref(_desc(50208, 768, 768, hint=224, **act))) == 224
     assert lib.xp_gemm_tile_rows(C.byref(_desc(3072, 768, 18848, split=7))) == 256        # dW1: 36 tiles x 7 slabs
