@@ -258,10 +258,9 @@ struct DirectEpi {
     for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[e], 0x128 /* row_ror:8 */, 0xF, 0xF, false);
     return r;
   }
-  __device__ __forceinline__ void store_lines(__amdgpu_buffer_rsrc_t r, unsigned ld, const unsigned (&col)[NG], const f32x8& v0,
-                                              const f32x8& v1, unsigned m, int i16) const {
+  __device__ __forceinline__ void store_lines(__amdgpu_buffer_rsrc_t r, unsigned ld, const unsigned (&col)[NG], const u32x4& p0,
+                                              const u32x4& p1, unsigned m, int i16) const {
     const bool lo = (i16 & 8) == 0;
-    const u32x4 p0 = pack8(v0), p1 = pack8(v1);
     const u32x4 got = ror8(lo ? p1 : p0);
     const u32x4 d1 = lo ? p0 : got, d2 = lo ? got : p1;
     const unsigned c = lo ? col[0] : col[1];
@@ -295,18 +294,26 @@ struct DirectEpi {
     }
     return v;
   }
-  // one row sub-tile of the lane, both column groups: arithmetic, then two full-line store instructions (fp32 outputs: as finish())
-  __device__ __forceinline__ void finish2(f32x8 (&o)[NG], const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3,
+  // one row sub-tile of the lane, both column groups: arithmetic (column sums of the unrounded values into `cs` when asked), packed
+  // at once to 16 bytes per group, then two full-line store instructions (fp32 outputs: as finish())
+  template <bool COLSUM>
+  __device__ __forceinline__ void finish2(f32x8 (&cs)[NG], bool row_ok, const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3,
                                           const Raw8<T> (&pre)[NG], unsigned m, int i16) const {
     if constexpr (F32) {
-      o[0] = finish(f32x8{a0, a1}, pre[0], m, 0);
-      o[1] = finish(f32x8{a2, a3}, pre[1], m, 1);
+      const f32x8 o0 = finish(f32x8{a0, a1}, pre[0], m, 0), o1 = finish(f32x8{a2, a3}, pre[1], m, 1);
+      if constexpr (COLSUM) { if (row_ok) { cs[0].lo += o0.lo; cs[0].hi += o0.hi; cs[1].lo += o1.lo; cs[1].hi += o1.hi; } }
     } else {
-      f32x8 xv[NG];
-      o[0] = math(f32x8{a0, a1}, pre[0], m, 0, xv[0]);
-      o[1] = math(f32x8{a2, a3}, pre[1], m, 1, xv[1]);
-      if constexpr (EPI == XP_EPI_BIAS_GELU) { if (keep_aux) store_lines(rx, ld_x, col_x, xv[0], xv[1], m, i16); }
-      store_lines(rc, ld_c, col_c, o[0], o[1], m, i16);
+      u32x4 pc[NG], px[NG];
+#pragma unroll
+      for (int hb = 0; hb < NG; ++hb) {
+        f32x8 xv;
+        const f32x8 o = math(hb == 0 ? f32x8{a0, a1} : f32x8{a2, a3}, pre[hb], m, hb, xv);
+        if constexpr (COLSUM) { if (row_ok) { cs[hb].lo += o.lo; cs[hb].hi += o.hi; } }
+        pc[hb] = pack8(o);
+        if constexpr (EPI == XP_EPI_BIAS_GELU) px[hb] = pack8(xv);
+      }
+      if constexpr (EPI == XP_EPI_BIAS_GELU) { if (keep_aux) store_lines(rx, ld_x, col_x, px[0], px[1], m, i16); }
+      store_lines(rc, ld_c, col_c, pc[0], pc[1], m, i16);
     }
   }
 #endif
@@ -465,13 +472,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
         }
       }
 #if XP_GEMM256_EPI_LINES
-      f32x8 o2[2];
-      de.finish2(o2, acc[0][mt], acc[1][mt], acc[2][mt], acc[3][mt], pre[mt & 1], mrow + mt * 16, i16);
-      if constexpr (COLSUM) {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
-          if (mrow + mt * 16 < (unsigned)p.M) { cs[hb].lo += o2[hb].lo; cs[hb].hi += o2[hb].hi; }
-      }
+      de.template finish2<COLSUM>(cs, mrow + mt * 16 < (unsigned)p.M, acc[0][mt], acc[1][mt], acc[2][mt], acc[3][mt], pre[mt & 1],
+                                  mrow + mt * 16, i16);
 #else
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
@@ -571,10 +573,10 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_persist_kernel(KParams p) {
 #if XP_GEMM256_EPI_LINES
         const Raw8<T> none2[2] = {};
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          f32x8 o2[2];
-          de.finish2(o2, acc[0][mt], acc[1][mt], acc[2][mt], acc[3][mt], none2, mrow + mt * 16, i16);
-        }
+        f32x8 nocs[2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          de.template finish2<false>(nocs, false, acc[0][mt], acc[1][mt], acc[2][mt], acc[3][mt], none2, mrow + mt * 16, i16);
 #else
         const Raw8<T> none{};
 #pragma unroll
