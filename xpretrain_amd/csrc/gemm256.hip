@@ -572,7 +572,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_persist_kernel(KParams p) {
         const unsigned mrow = (unsigned)(m0 + wm * WR) + i16;
 #if XP_GEMM256_EPI_LINES
         const Raw8<T> none2[2] = {};
-#pragma unroll
         f32x8 nocs[2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
