@@ -49,12 +49,6 @@
 //   k-strided    half [64 k][256 B]:      32-byte block' = block ^ ((k&3) | ((k>>3)&1)<<2)   (ds_read_b64_tr_b16)
 #include "common.h"
 #include "gemm_common.h"
-
-// Build-time experiment (default 0 = the validated epilogue): lane-exchanged full-line stores in the direct epilogue, see
-// DirectEpi::store_lines.  Judged on whole-step timings of two builds (tools/instep_ab.py name@tree), DESIGN.md 6.0c.
-#ifndef XP_GEMM256_EPI_LINES
-#define XP_GEMM256_EPI_LINES 0
-#endif
 #include <stdlib.h>
 #include <mutex>
 
@@ -242,81 +236,6 @@ struct DirectEpi {
     bstore8<T, F32>(rc, off_c(m, hb), v);
     return v;
   }
-#if XP_GEMM256_EPI_LINES
-  // Full-line stores (bf16 outputs): a lane holds 16 bytes of BOTH column groups of its row, so a plain store instruction covers
-  // 16 rows x 64 contiguous bytes.  Lanes i16 and i16 ^ 8 of a 16-lane DPP row exchange one group each (row_ror:8): lanes i16 < 8
-  // then hold group 0 of rows i16 and i16 + 8, lanes i16 >= 8 group 1 of rows i16 - 8 and i16 -- one store instruction covers
-  // 8 rows x 128 contiguous bytes, the next one the other 8 rows: whole 128-byte lines per request.
-  static __device__ __forceinline__ u32x4 pack8(const f32x8& v) {
-    const bf16x8 o = {(bf16_t)v.lo[0], (bf16_t)v.lo[1], (bf16_t)v.lo[2], (bf16_t)v.lo[3],
-                      (bf16_t)v.hi[0], (bf16_t)v.hi[1], (bf16_t)v.hi[2], (bf16_t)v.hi[3]};
-    return __builtin_bit_cast(u32x4, o);
-  }
-  static __device__ __forceinline__ u32x4 ror8(const u32x4& x) {
-    u32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[e], 0x128 /* row_ror:8 */, 0xF, 0xF, false);
-    return r;
-  }
-  __device__ __forceinline__ void store_lines(__amdgpu_buffer_rsrc_t r, unsigned ld, const unsigned (&col)[NG], const u32x4& p0,
-                                              const u32x4& p1, unsigned m, int i16) const {
-    const bool lo = (i16 & 8) == 0;
-    const u32x4 got = ror8(lo ? p1 : p0);
-    const u32x4 d1 = lo ? p0 : got, d2 = lo ? got : p1;
-    const unsigned c = lo ? col[0] : col[1];
-    const unsigned r1 = lo ? m : m - 8;
-    __builtin_amdgcn_raw_buffer_store_b128(d1, r, c == EPI_OOB ? EPI_OOB : r1 * ld + c, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(d2, r, c == EPI_OOB ? EPI_OOB : (r1 + 8) * ld + c, 0, 0);
-  }
-  // the arithmetic of finish() without its stores; xv: what goes to the aux output (BIAS_GELU: the pre-activation)
-  __device__ __forceinline__ f32x8 math(f32x8 v, const Raw8<T>& pre, unsigned m, int hb, f32x8& xv) const {
-    if constexpr (Tr::bias) { v.lo += bias[hb].lo; v.hi += bias[hb].hi; }
-    if constexpr (Tr::scale) { v.lo *= cs[hb][0]; v.hi *= cs[hb][1]; }
-    if constexpr (EPI == XP_EPI_BIAS_GELU) {
-      xv = v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v.lo[e] = quick_gelu_f(v.lo[e]); v.hi[e] = quick_gelu_f(v.hi[e]); }
-    } else if constexpr (EPI == XP_EPI_BIAS_RESID) {
-      int64_t sb;
-      if (side.on() && col_c[hb] != EPI_OOB && side.hit(m, sb)) {
-        const int64_t n = ncol + hb * GSTRIDE;
-        const f32x8 r = load8(side.rin + sb + n);
-        v.lo += r.lo; v.hi += r.hi;
-        store8(side.out + sb + n, v);
-      } else {
-        const f32x8 r = raw8_f32<T>(pre);
-        v.lo += r.lo; v.hi += r.hi;
-      }
-    } else if constexpr (EPI == XP_EPI_GELU_BWD) {
-      const f32x8 r = raw8_f32<T>(pre);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v.lo[e] *= quick_gelu_grad_f(r.lo[e]); v.hi[e] *= quick_gelu_grad_f(r.hi[e]); }
-    }
-    return v;
-  }
-  // one row sub-tile of the lane, both column groups: arithmetic (column sums of the unrounded values into `cs` when asked), packed
-  // at once to 16 bytes per group, then two full-line store instructions (fp32 outputs: as finish())
-  template <bool COLSUM>
-  __device__ __forceinline__ void finish2(f32x8 (&cs)[NG], bool row_ok, const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3,
-                                          const Raw8<T> (&pre)[NG], unsigned m, int i16) const {
-    if constexpr (F32) {
-      const f32x8 o0 = finish(f32x8{a0, a1}, pre[0], m, 0), o1 = finish(f32x8{a2, a3}, pre[1], m, 1);
-      if constexpr (COLSUM) { if (row_ok) { cs[0].lo += o0.lo; cs[0].hi += o0.hi; cs[1].lo += o1.lo; cs[1].hi += o1.hi; } }
-    } else {
-      u32x4 pc[NG], px[NG];
-#pragma unroll
-      for (int hb = 0; hb < NG; ++hb) {
-        f32x8 xv;
-        const f32x8 o = math(hb == 0 ? f32x8{a0, a1} : f32x8{a2, a3}, pre[hb], m, hb, xv);
-        if constexpr (COLSUM) { if (row_ok) { cs[hb].lo += o.lo; cs[hb].hi += o.hi; } }
-        pc[hb] = pack8(o);
-        if constexpr (EPI == XP_EPI_BIAS_GELU) px[hb] = pack8(xv);
-      }
-      if constexpr (EPI == XP_EPI_BIAS_GELU) { if (keep_aux) store_lines(rx, ld_x, col_x, px[0], px[1], m, i16); }
-      store_lines(rc, ld_c, col_c, pc[0], pc[1], m, i16);
-    }
-  }
-#endif
 };
 
 // The k-loop of one output tile: on entry B0(0) and half-tiles 0..3 are in flight with B0(0), A0(0), B1(0) landed in every wave
@@ -471,10 +390,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
           for (int hb = 0; hb < 2; ++hb) pre[(mt + 1) & 1][hb] = de.load_pre(mrow + (mt + 1) * 16, hb);
         }
       }
-#if XP_GEMM256_EPI_LINES
-      de.template finish2<COLSUM>(cs, mrow + mt * 16 < (unsigned)p.M, acc[0][mt], acc[1][mt], acc[2][mt], acc[3][mt], pre[mt & 1],
-                                  mrow + mt * 16, i16);
-#else
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const f32x8 o = de.finish(f32x8{acc[hb * 2][mt], acc[hb * 2 + 1][mt]}, pre[mt & 1][hb], mrow + mt * 16, hb);
@@ -482,7 +397,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
           if (mrow + mt * 16 < (unsigned)p.M) { cs[hb].lo += o.lo; cs[hb].hi += o.hi; }     // rows >= M are not outputs
         }
       }
-#endif
     }
     if constexpr (COLSUM) {
       // the 16 lanes i16 = 0..15 of a column octet hold different rows: butterfly over lane bits 0..3, then lane i16 == 0
@@ -570,19 +484,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_persist_kernel(KParams p) {
       if constexpr (!EpiTraits<EPI>::pre && !F32 && !decltype(cs_c)::value) {      // (the launcher sends nothing else here)
         const DirectEpi<EPI, false> de(p, (void*)Ct, n0 + wn * 64 + g * 8);
         const unsigned mrow = (unsigned)(m0 + wm * WR) + i16;
-#if XP_GEMM256_EPI_LINES
-        const Raw8<T> none2[2] = {};
-        f32x8 nocs[2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          de.template finish2<false>(nocs, false, acc[0][mt], acc[1][mt], acc[2][mt], acc[3][mt], none2, mrow + mt * 16, i16);
-#else
         const Raw8<T> none{};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int hb = 0; hb < 2; ++hb) de.finish(f32x8{acc[hb * 2][mt], acc[hb * 2 + 1][mt]}, none, mrow + mt * 16, hb);
-#endif
         if (has_next) wait_vmcnt<4 + 2 * MT>();      // 2*MT stores (at least) are younger than the 10 DMA pieces
       }
     });
