@@ -1,0 +1,54 @@
+"""What the text tower costs while it overlaps the video tower: forward + loss + backward of the cfg #2 step (no optimizer) with the
+real text tower against the same with the text transformer's launches skipped (its pooled output replaced by a cached constant; the
+projection and the loss still run).  Interleaved rounds on one box.  Usage: python tools/text_tower_cost.py [steps] [rounds]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+import bench as B
+from oracle import clipvip_oracle as O
+from xpretrain_amd import distributed as D
+from xpretrain_amd.modeling import VidCLIP
+from xpretrain_amd.optimization import NCELearnableTempLoss
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+torch.manual_seed(1234)
+model = VidCLIP(B.Args(O.vit_b_config(16, 224))).to(dev).train()
+loss_fn = NCELearnableTempLoss()
+video, ids, mask = O.synthetic_inputs(8, 12, 224, 32, seed=4321)
+video, ids, mask = video.to(dev), ids.to(dev), mask.to(dev)
+ls = model.clipmodel.logit_scale
+text_model = model.clipmodel.text_model
+real_forward = text_model.forward
+with torch.no_grad():
+    ref = real_forward(input_ids=ids, attention_mask=mask)
+cached = type(ref)(last_hidden_state=None, pooler_output=ref["pooler_output"].detach().clone(), hidden_states=None, attentions=None)
+
+
+def step():
+    out = model(video, ids, mask)
+    vis, txt = D.gather_features(out["vis_features"], out["text_features"])
+    loss = loss_fn(vis, txt, ls)
+    loss.backward()
+    for p in model.parameters():
+        p.grad = None
+    return loss
+
+
+def timed(skip):
+    text_model.forward = (lambda *a, **k: cached) if skip else real_forward
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+for r in range(rounds):
+    a, b = timed(False), timed(True)
+    print(f"round {r}: forward+loss+backward {a:.3f} ms with the text tower (overlapped), {b:.3f} ms with its launches skipped: {a - b:+.3f} ms")
+text_model.forward = real_forward
