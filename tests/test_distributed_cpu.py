@@ -233,3 +233,76 @@ def test_layout_groups_and_gradient_sinks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
+
+
+# ---------------------------------------------------------------------------------------------- optimizer state: source rank untouched
+def _optstate_worker(rank, world, port, q):
+    """broadcast_optimizer_state must never rewrite the SOURCE rank's tensors (a strided moment, or a scalar tensor living on
+    another device kind than its parameter, used to be replaced by zeros on rank 0 and the zeros broadcast)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from xpretrain_amd import distributed as D
+    D.init_from_env("gloo")
+    p = torch.nn.Parameter(torch.zeros(4, 3))
+    opt = torch.optim.SGD([p], lr=0.1 * (rank + 1))
+    ok = True
+    if rank == 0:
+        strided = torch.arange(12.0).reshape(3, 4).t()          # [4, 3], not contiguous (a preserve_format moment)
+        opt.state[p] = {"exp_avg": strided, "step": torch.tensor(7.0), "tag": "x"}
+        ptr = strided.data_ptr()
+    else:
+        opt.state[p] = {"exp_avg": torch.full((4, 3), -1.0).t().contiguous().t(), "stale": torch.ones(2)}
+    D.broadcast_optimizer_state(opt, src=0)
+    st = opt.state[p]
+    want = torch.arange(12.0).reshape(3, 4).t()
+    ok = ok and torch.equal(st["exp_avg"], want) and float(st["step"]) == 7.0 and st["tag"] == "x" and "stale" not in st
+    ok = ok and abs(opt.param_groups[0]["lr"] - 0.1) < 1e-12
+    if rank == 0:
+        ok = ok and st["exp_avg"].data_ptr() == ptr and not st["exp_avg"].is_contiguous()      # the very same tensor, untouched
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_optimizer_state_keeps_the_source_state():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_optstate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def test_gradient_sink_is_claimed_once_per_backward():
+    """functional._claim_sink: a layer applied twice in ONE backward graph (VidCLIP's second image / caption pass) may write the
+    sink once; the second application gets a private buffer and autograd adds the two -- g1 + g2, not 2 * g2."""
+    import xpretrain_amd.functional as XF
+    w = torch.nn.Parameter(torch.ones(3))
+    sink = torch.zeros(3)
+    key = XF.grad_sink_key((w,))
+
+    class Layer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, scale):
+            ctx.scale = scale
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            flat = XF._claim_sink(key, sink, 3, sink.device, (w,))
+            if flat is None:
+                flat = torch.empty(3)
+            flat.copy_(torch.full((3,), float(ctx.scale)))       # the "kernel" writes this call's gradient
+            return g, flat.view(3), None
+
+    x = torch.ones(3, requires_grad=True)
+    for step in range(2):                                        # claims must not leak from one backward() into the next
+        w.grad = None
+        (Layer.apply(x, w, 1.0).sum() + Layer.apply(x, w, 10.0).sum()).backward()
+        assert torch.equal(w.grad, torch.full((3,), 11.0)), w.grad
+    assert XF._claim_sink(key, sink, 3, sink.device, (w,)) is None      # outside backward(): never
+    XF.release_grad_sinks()

@@ -285,6 +285,9 @@ class GradBucketReducer:
             p.grad = None
         for b in self.buckets:
             b["ready"] = 0
+        if self._sinks:
+            from . import functional as XF
+            XF.release_grad_sinks()
 
     def remove(self):
         for h in self._hooks:
@@ -294,6 +297,7 @@ class GradBucketReducer:
             for key in self._sinks:
                 XF.GRAD_SINKS.pop(key, None)
             self._sinks = []
+            XF.release_grad_sinks()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
@@ -321,8 +325,17 @@ def broadcast_optimizer_state(optimizer: torch.optim.Optimizer, src: int = 0):
         meta = {"groups": [{k: v for k, v in g.items() if k != "params"} for g in optimizer.param_groups], "state": []}
         for p in params:
             st = optimizer.state.get(p, {})
-            meta["state"].append({k: (("tensor", tuple(v.shape), str(v.dtype).replace("torch.", "")) if torch.is_tensor(v) else ("value", v))
-                                  for k, v in st.items()})
+            ent = {}
+            for k, v in st.items():
+                if not torch.is_tensor(v):
+                    ent[k] = ("value", v)
+                elif v.device != p.device:
+                    # e.g. torch.optim.Adam(W)'s ``step``: a CPU scalar tensor beside GPU parameters -- it travels by value
+                    # inside this object broadcast and is re-created on ITS device kind, never on the parameter's
+                    ent[k] = ("host_tensor", v.detach().cpu())
+                else:
+                    ent[k] = ("tensor", tuple(v.shape), str(v.dtype).replace("torch.", ""))
+            meta["state"].append(ent)
         box = [meta]
     else:
         box = [None]
@@ -344,11 +357,17 @@ def broadcast_optimizer_state(optimizer: torch.optim.Optimizer, src: int = 0):
         for k, desc in ms.items():
             if desc[0] == "value":
                 st[k] = desc[1]
+            elif desc[0] == "host_tensor":
+                if me != src:
+                    st[k] = desc[1].clone()
             else:
                 _, shape, dtype = desc
                 dtype = getattr(torch, dtype)
                 t = st.get(k)
-                if not torch.is_tensor(t) or tuple(t.shape) != shape or t.dtype != dtype or t.device != p.device or not t.is_contiguous():
+                # the SOURCE rank's tensors are never touched (they ARE the state being sent); a receiver keeps its own tensor
+                # whenever shape / dtype / device fit -- strides may differ (preserve_format moments of a strided parameter):
+                # the payload is copied in through a contiguous staging buffer below
+                if me != src and (not torch.is_tensor(t) or tuple(t.shape) != shape or t.dtype != dtype or t.device != p.device):
                     t = st[k] = torch.zeros(shape, dtype=dtype, device=p.device)
                 by_dtype.setdefault((dtype, p.device), []).append(t)
     cap = 64 << 20
@@ -358,12 +377,16 @@ def broadcast_optimizer_state(optimizer: torch.optim.Optimizer, src: int = 0):
             chunk, nbytes = [], 0
             while i < len(ts) and (not chunk or nbytes + ts[i].numel() * ts[i].element_size() <= cap):
                 chunk.append(ts[i]); nbytes += ts[i].numel() * ts[i].element_size(); i += 1
-            flat = torch.cat([t.reshape(-1) for t in chunk]) if len(chunk) > 1 else chunk[0].reshape(-1)
+            if me == src:
+                flat = torch.cat([t.detach().reshape(-1) for t in chunk])          # (a copy: the source state stays as it is)
+            else:
+                flat = torch.empty(sum(t.numel() for t in chunk), dtype=dtype, device=device)
             dist.broadcast(flat, src)
-            if len(chunk) > 1 and me != src:
+            if me != src:
                 off = 0
-                for t in chunk:
-                    t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+                with torch.no_grad():
+                    for t in chunk:
+                        t.copy_(flat[off:off + t.numel()].view(t.shape)); off += t.numel()
     if hasattr(optimizer, "_plan"):
         optimizer._plan = None        # optimization.AdamW caches moment addresses
 

@@ -268,12 +268,36 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
 # Gradient sinks (distributed.GradBucketReducer(layout_groups=...)): flat fp32 buffers -- slices of the reducer's all-reduce
 # buckets -- keyed by the storage of a layer's 16 parameters.  The native layer backward writes its parameter gradients straight
 # into the sink instead of a private buffer, so the bucket never needs a pack copy.  Used only while every parameter of the layer
-# has ``.grad is None`` (gradient accumulation: the second micro-step must not overwrite what autograd is about to add to).
+# has ``.grad is None`` (gradient accumulation: the second micro-step must not overwrite what autograd is about to add to) and only
+# by the first application of the layer in a backward pass (_claim_sink).
 GRAD_SINKS = {}
+# One backward pass may hand a sink to ONE layer call only.  A layer applied twice in one graph (VidCLIP.forward's second image /
+# caption pass, VidCLIP.py:70-79) backpropagates through both applications before the AccumulateGrad nodes of the shared parameters
+# run, so ``p.grad is None`` still holds at the second call: writing the sink again would overwrite the views the first call
+# returned and autograd would sum two aliases (2 * g2 instead of g1 + g2).  The claim is keyed by autograd's graph-task id (one id
+# per ``backward()`` call), so it needs no reset between steps; the second application gets a private buffer and autograd adds it.
+_SINK_CLAIMS = {}
 
 
 def grad_sink_key(params16):
     return tuple(p.data_ptr() for p in params16)
+
+
+def _claim_sink(key, sink, numel, device, params):
+    """The sink of ``key`` if this layer call may write its gradients straight into it, else None (private buffer)."""
+    if sink is None or sink.numel() != numel or sink.device != device or not all(p.grad is None for p in params):
+        return None
+    task = torch._C._current_graph_task_id()
+    if task < 0 or _SINK_CLAIMS.get(key) == task:      # outside a backward pass / second application in this pass
+        return None
+    _SINK_CLAIMS[key] = task
+    return sink
+
+
+def release_grad_sinks():
+    """forget the per-backward sink claims (GradBucketReducer.zero_grad / remove; graph-task ids restart in a new process only,
+    so this is hygiene, not a correctness requirement)"""
+    _SINK_CLAIMS.clear()
 
 
 def layer_grad_groups(model):
@@ -295,9 +319,7 @@ def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_ma
     dx = torch.empty_like(x)
     flat = None
     if GRAD_SINKS and ctx.sink_key is not None and all(need[1:17]):
-        sink = GRAD_SINKS.get(ctx.sink_key)
-        if sink is not None and sink.numel() == plan.gtotal and sink.device == dev and all(p.grad is None for p in ctx.sink_params):
-            flat = sink
+        flat = _claim_sink(ctx.sink_key, GRAD_SINKS.get(ctx.sink_key), plan.gtotal, dev, ctx.sink_params)
     if flat is None:
         flat = torch.empty(plan.gtotal, dtype=torch.float32, device=dev)
     parts = flat.split_with_sizes(plan.gsizes)
