@@ -100,6 +100,11 @@ int xp_gemm(const XpGemmDesc* desc, void* stream);
  * of workgroups of the kernel family xp_gemm will pick for `desc` (desc->split_k and the data pointers are
  * ignored).  The value is always accepted by xp_gemm (whole k-steps per slab, no empty slab); 1 = no split. */
 int32_t xp_gemm_auto_split(const XpGemmDesc* desc);
+/* CUs the split-K planning may fill (64..256, default 256 or $XPRETRAIN_CU_BUDGET).  A data-parallel run lowers it by the number
+ * of workgroups its collective library keeps resident during the backward pass (hvd.DistributedOptimizer's all-reduce,
+ * run_pretrain.py:224-227,379; RCCL's gfx950 kernels own a CU per workgroup) so that a dW launch still fits one round. */
+int xp_set_cu_budget(int32_t cus);
+int32_t xp_get_cu_budget(void);
 /* number of partial rows xp_gemm writes to desc->colsum_partials, or 0 if the fused column sums are not available
  * for this problem (desc->colsum_partials itself is ignored here) */
 int64_t xp_gemm_colsum_rows(const XpGemmDesc* desc);
@@ -396,6 +401,8 @@ int xp_probe_pk_f32(void* err /*15*64*2 u32, zeroed by the caller*/, int32_t ite
 /* memory-bound copy of nbytes (multiple of 16) repeated iters times by `blocks` 256-thread workgroups: a one-GPU stand-in for a
  * collective's channel kernels beside the backward pass (hvd.DistributedOptimizer's all-reduce, run_pretrain.py:224-227) */
 int xp_probe_stream_copy(void* dst, const void* src, int64_t nbytes, int32_t blocks, int32_t iters, void* stream);
+/* the same copy in a kernel with the register / LDS footprint of RCCL's gfx950 collective kernel (one wave per SIMD, 19,744 B LDS) */
+int xp_probe_stream_copy_fat(void* dst, const void* src, int64_t nbytes, int32_t blocks, int32_t iters, void* stream);
 int xp_probe_tr16(const void* in /*4096 u16*/, const int32_t* lane_byte_off /*64*/, void* out /*64*4 u16*/, void* stream);
 
 #ifdef __cplusplus

@@ -32,15 +32,15 @@ src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 dst = torch.empty_like(src)
 
 
-def step(blocks=0, iters=1):
+def step(blocks=0, iters=1, fn="xp_probe_stream_copy"):
     with torch.no_grad():
         ls.clamp_(0, math.log(200.0))
     out = model(video, ids, mask)
     loss = loss_fn(out["vis_features"], out["text_features"], ls)
     if blocks:
         side.wait_stream(torch.cuda.current_stream())
-        L.check(L.lib().xp_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, iters,
-                                             C.c_void_p(side.cuda_stream)), "xp_probe_stream_copy")
+        L.check(getattr(L.lib(), fn)(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, iters,
+                                     C.c_void_p(side.cuda_stream)), fn)
     loss.backward()
     if blocks:
         torch.cuda.current_stream().wait_stream(side)
@@ -63,12 +63,17 @@ def timed(f, n):
 
 base = timed(step, steps)
 print(f"step alone: {base:.3f} ms")
-for blocks in (16, 32, 64):
-    def alone():
-        L.check(L.lib().xp_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, 1,
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "copy")
-    t_copy = timed(alone, 5)
-    # 2 x 7/8 x 598 MB is what a ring all-reduce moves per GPU on 8 GPUs: one read + one write pass of the buffer ~ iters = 1
-    t = timed(lambda: step(blocks, 1), steps)
-    print(f"{blocks:3d} copy workgroups: copy alone {t_copy:.3f} ms ({2 * nbytes / t_copy / 1e6:.0f} GB/s read+write); step with the copy "
-          f"beside backward {t:.3f} ms (+{t - base:.3f} ms, {100 * (t - base) / base:.1f} %); serial sum would be {base + t_copy:.3f} ms")
+# "thin": a copy kernel with a handful of registers (fits beside a GEMM workgroup's waves); "rccl footprint": the same copy in a
+# kernel with the resources of RCCL's gfx950 collective kernel (csrc/probe.hip: 288 registers per lane = one wave per SIMD, 19,744 B
+# LDS) -- it cannot share a CU with a 256x256-GEMM workgroup, so its workgroups take whole CUs away from the GEMMs for as long as
+# the copy lasts, which is what a bucket all-reduce beside the backward pass does.
+for fn, label in (("xp_probe_stream_copy", "thin"), ("xp_probe_stream_copy_fat", "rccl footprint")):
+    for blocks in (8, 16, 32, 64):
+        def alone():
+            L.check(getattr(L.lib(), fn)(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, 1,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "copy")
+        t_copy = timed(alone, 5)
+        # 2 x 7/8 x 598 MB is what a ring all-reduce moves per GPU on 8 GPUs: one read + one write pass of the buffer ~ iters = 1
+        t = timed(lambda: step(blocks, 1, fn), steps)
+        print(f"{label:14s} {blocks:3d} copy workgroups: copy alone {t_copy:.3f} ms ({2 * nbytes / t_copy / 1e6:.0f} GB/s read+write); step with "
+              f"the copy beside backward {t:.3f} ms (+{t - base:.3f} ms, {100 * (t - base) / base:.1f} %); serial sum would be {base + t_copy:.3f} ms")

@@ -91,6 +91,8 @@ SIGNATURES = {
     "xp_last_error": (C.c_char_p, []),
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
     "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
+    "xp_set_cu_budget": (i32, [i32]),
+    "xp_get_cu_budget": (i32, []),
     "xp_gemm_colsum_rows": (i64, [C.POINTER(XpGemmDesc)]),
     "xp_gemm_tile_rows": (i32, [C.POINTER(XpGemmDesc)]),
     "xp_colsum_partial_rows": (i64, [i64, i64]),
@@ -150,6 +152,7 @@ SIGNATURES = {
     "xp_probe_mfma_f32": (i32, [vp, vp, vp, vp]),
     "xp_probe_tr16": (i32, [vp, vp, vp, vp]),
     "xp_probe_stream_copy": (i32, [vp, vp, i64, i32, i32, vp]),
+    "xp_probe_stream_copy_fat": (i32, [vp, vp, i64, i32, i32, vp]),
     "xp_probe_pk_f32": (i32, [vp, i32, i32, C.c_uint32, vp]),
 }
 

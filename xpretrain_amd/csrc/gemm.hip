@@ -569,7 +569,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.bias = d->bias; kp.scale = d->scale; kp.scale_cols = d->scale_cols;
   kp.resid = d->resid; kp.ldr = d->ldr; kp.aux = d->aux; kp.ldaux = d->ldaux;
   kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
-  kp.dbg = g_gemm_trace;
+  kp.dbg = g_gemm_trace; kp.flat_split = 0;
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
   kp.fast_epi = (kp.wide && xp_gemm_fast_epi_ok(d)) ? 1 : 0;
   kp.colsum = d->colsum_partials;
@@ -641,12 +641,28 @@ static int valid_split(int64_t K, int64_t s0, int64_t ke) {
   return (int)cdiv(K, kps);
 }
 
+// CUs the GEMM planning may count on (default: all 256).  A data-parallel run reserves the CUs its collective kernels occupy:
+// RCCL's gfx950 kernels need one wave per SIMD with > 256 registers per lane, so each of their workgroups owns a CU for as long as
+// a bucket all-reduce lasts (tools/contention_probe.py); a 252-workgroup dW launch would then need a second round for 12 tiles.
+static int g_cu_budget = [] {
+  const char* e = getenv("XPRETRAIN_CU_BUDGET");
+  const int v = e ? atoi(e) : 256;
+  return v >= 64 && v <= 256 ? v : 256;
+}();
+extern "C" int xp_set_cu_budget(int32_t cus) {
+  XP_REQUIRE(cus >= 64 && cus <= 256, "xp_set_cu_budget: %d not in 64..256", cus);
+  g_cu_budget = cus;
+  return XP_OK;
+}
+extern "C" int32_t xp_get_cu_budget(void) { return g_cu_budget; }
+
 extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 1;
   const int esz = d->in_dtype == XP_BF16 ? 2 : 4;
   const int64_t ke = BKB / esz;
   const int64_t t256 = cdiv(d->M, 256) * cdiv(d->N, 256);
-  int64_t s0 = 256 / t256 < d->K / 512 ? 256 / t256 : d->K / 512;
+  const int64_t cus = g_cu_budget;
+  int64_t s0 = cus / t256 < d->K / 512 ? cus / t256 : d->K / 512;
   const int s256 = valid_split(d->K, s0, 64);
   if (xp_gemm256_wanted(d, s256)) return s256;
   const int64_t t128 = cdiv(d->M, BM) * cdiv(d->N, BN);

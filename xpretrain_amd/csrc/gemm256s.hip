@@ -105,12 +105,22 @@ __global__ __launch_bounds__(NTH, 2) void gemm256s_kernel(KParams p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = xcd_remap(blockIdx.x, nwg, p.xcd_remap);
+  // Split-K launches (dW: k = the token dimension) with flat_split > 0 use a 1-D grid over (k-chunk, tile) pairs, CHUNK-MAJOR in
+  // the XCD-contiguous order: an XCD's ~32 concurrent workgroups are (almost) all the tiles of ONE k-chunk, so its L2 fetches every
+  // operand panel of that chunk once.  With the (tile, z) grid each XCD held ~4.5 tiles of EVERY chunk and each of the chunk's
+  // panels was fetched by every XCD that touched it: 386 MB from the fabric for 145 MB of operands at dW1 (PMC, profiles/r03y).
+  int bid, zs, nsplit;
+  if (p.flat_split > 0) {
+    const int l = xcd_remap(blockIdx.x, nwg * p.flat_split, 1);
+    zs = l / nwg; bid = l - zs * nwg; nsplit = p.flat_split;
+  } else {
+    bid = xcd_remap(blockIdx.x, nwg, p.xcd_remap); zs = blockIdx.z; nsplit = gridDim.z;
+  }
   int tm, tn;
   tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
   const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
 
-  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kbeg = (int64_t)zs * p.k_per_split;
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
   const int nk = (int)((kend - kbeg + KE - 1) / KE);       // >= 2 (launcher)
 
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm256s_kernel(KParams p) {
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bool trace = p.dbg != nullptr && (int)blockIdx.x == nwg / 2 && blockIdx.z == 0 && wave == 0;
+  const bool trace = p.dbg != nullptr && bid == nwg / 2 && zs == 0 && wave == 0;
   unsigned long long* tr = p.dbg;
   if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
 
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm256s_kernel(KParams p) {
   const int i16 = lane & 15, g = lane >> 4;
   float* Cf = reinterpret_cast<float*>(p.C);
   T* Ct = reinterpret_cast<T*>(p.C);
-  if (gridDim.z > 1) Cf += (int64_t)blockIdx.z * p.M * p.N;
+  if (nsplit > 1) Cf += (int64_t)zs * p.M * p.N;
   auto stage_round = [&](int q) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -372,7 +382,9 @@ bool xp_gemm256s_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStr
   if (cdiv(k_last, KE) < 2) return false;                                         // the pipeline needs >= 2 k-tiles
   kp.tiles_m = (int)cdiv(d->M, TM); kp.tiles_n = (int)cdiv(d->N, TN);
   kp.group_n = kp.tiles_n;
-  dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
+  static const bool chunk_major = !getenv("XPRETRAIN_DW_CHUNK_MAJOR") || atoi(getenv("XPRETRAIN_DW_CHUNK_MAJOR")) != 0;
+  kp.flat_split = (split > 1 && chunk_major) ? split : 0;
+  dim3 grid(kp.tiles_m * kp.tiles_n * (kp.flat_split ? split : 1), 1, kp.flat_split ? 1 : split);
   if (!d->a_kstrided && !d->b_kstrided)      launch_one<false, false>(kp, grid, st);
   else if (!d->a_kstrided && d->b_kstrided)  launch_one<false, true>(kp, grid, st);
   else if (d->a_kstrided && d->b_kstrided)   launch_one<true, true>(kp, grid, st);

@@ -30,6 +30,7 @@ struct KParams {
   float* colsum;             // optional [2 * tiles_m][N] column sums of the finished outputs per wave row block (256 family)
   const float* rside; float* oside; unsigned side_S, side_M;   // BIAS_RESID: fp32 side rows of the residual stream (XpGemmDesc)
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
+  int flat_split;            // gemm256s split-K launches: > 0 = the grid is 1-D over (k-chunk, tile), chunk-major per XCD (see kernel)
 };
 
 

@@ -7,6 +7,8 @@
 // Python / ctypes time against 16.7 ms of GPU time (BENCH_r01); from C++ a launch costs 3-4 us.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -55,6 +57,38 @@ struct Defer {             // the layer's deferred second-level reductions (bias
     s.in = in; s.out = out; s.stride = stride; s.nrows = nrows; s.width = width; s.accumulate = 0; s.reserved = 0;
   }
 };
+
+// ---- weight-gradient GEMMs on a second stream (default; XPRETRAIN_WGRAD_STREAM=0 puts them back on the caller's stream) ------
+// The four dW GEMMs of a layer (+ their split-K reduces) are off the critical path of the backward pass: nothing in the layer
+// reads them.  On a stream of their own they run BESIDE the dX chain (GEMM -> LayerNorm -> GEMM -> attention -> GEMM -> LayerNorm):
+// their workgroups take the CUs the 222-tile dX GEMMs leave idle, the tails / launch boundaries of either stream, and overlap the
+// HBM-bound LayerNorm / attention / reduce kernels with MFMA work.  Ordering is by events only; the main stream joins the side
+// stream before the call returns, so buffer lifetimes (workspace reuse by the next layer, the caching allocator) are unchanged.
+// Measured in the step (interleaved whole-step A/B on one box, profiles/r04a_in_step_ab_wgrad_stream_chunk_major.txt):
+// 16.57 -> 16.22 ms per step; results are bit-identical (same kernels, same arguments).
+struct WgradSide {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // main-stream progress marks: entry, dpre, dx2, dqkv
+  hipEvent_t done = nullptr;                                  // side stream: last dW of the call finished
+  bool ok = false;
+};
+WgradSide* wgrad_side() {
+  static const bool on = !getenv("XPRETRAIN_WGRAD_STREAM") || atoi(getenv("XPRETRAIN_WGRAD_STREAM")) != 0;      // default on
+  if (!on) return nullptr;
+  static std::mutex mu;
+  static WgradSide per_dev[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  WgradSide& w = per_dev[dev];
+  if (!w.side) {
+    bool good = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&w.ev[i], hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+    w.ok = good;
+  }
+  return w.ok ? &w : nullptr;
+}
 
 int check_dims(const char* name, const XpLayerDims& d) {
   XP_REQUIRE(d.rows > 0 && d.D > 0 && d.Dff > 0 && d.B > 0 && d.S > 0 && d.heads > 0, "%s: empty dimension", name);
@@ -191,6 +225,19 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
   const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
   const int dt = d.dtype;
   Defer df;
+  // dW GEMMs beside the dX chain (video tower only: the text tower is 256 rows on a side stream of its own already)
+  WgradSide* wsd = (d.attn_mode == XP_ATTN_PROXY && rows >= 4096) ? wgrad_side() : nullptr;
+  hipStream_t mst = (hipStream_t)st;
+  void* wst = wsd ? (void*)wsd->side : st;
+  auto mark = [&](int i) -> int {           // side stream: everything the main stream has enqueued so far must finish first
+    if (!wsd) return XP_OK;
+    if (hipEventRecord(wsd->ev[i], mst) != hipSuccess || hipStreamWaitEvent(wsd->side, wsd->ev[i], 0) != hipSuccess) {
+      xp_set_error("xp_encoder_layer_bwd: event hand-off to the weight-gradient stream failed");
+      return XP_ERR_LAUNCH;
+    }
+    return XP_OK;
+  };
+  if ((rc = mark(0))) return rc;
 
   // ---- MLP: x3 = x2 + fc2(quick_gelu(fc1(LN2(x2))))
   XpGemmDesc g = gemm_desc(a->dx3, a->W2, dpre, rows, Dff, D, dt);            // dpre = (dx3 . W2) * quick_gelu'(pre)
@@ -205,11 +252,12 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
       df.add(cs_pre, a->db1, Dff, (int)r, (int)Dff);
     }
   }
-  if (a->dw2 && (rc = wgrad(a->dx3, a->act, a->dw2, rows, D, Dff, dt, slabs, p.slabs, st))) return rc;
+  if (a->dw2 && (rc = wgrad(a->dx3, a->act, a->dw2, rows, D, Dff, dt, slabs, p.slabs, wst))) return rc;
+  if ((rc = mark(1))) return rc;                                              // dpre is ready for dW1
   g = gemm_desc(dpre, a->W1, dh2, rows, D, Dff, dt);                          // dh2 = dpre . W1
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
-  if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, st))) return rc;
+  if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, wst))) return rc;
   // dx2 = dx3 + LN2'(dh2); partial rows [dgamma | dbeta | colsum(dx2) | colsum(dx3)] -- out_proj's and fc2's bias gradients
   if ((rc = xp_layernorm_bwd_partials_side(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 2, rows, D, dt,
                                            a->side_x2, a->side_S, a->side_M, a->side_M, ln2_part, p.ln2, st))) return rc;
@@ -217,17 +265,19 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
   df.add(ln2_part + D, a->dln2_b, 4 * D, (int)p.ln_rows, (int)D);
   df.add(ln2_part + 2 * D, a->dbo, 4 * D, (int)p.ln_rows, (int)D);
   df.add(ln2_part + 3 * D, a->db2, 4 * D, (int)p.ln_rows, (int)D);
+  if ((rc = mark(2))) return rc;                                              // dx2 is ready for dWo
   // ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
   g = gemm_desc(dx2, a->Wo, dattn, rows, D, D, dt);                           // dattn = dx2 . Wo
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
-  if (a->dwo && (rc = wgrad(dx2, a->attn_o, a->dwo, rows, D, D, dt, slabs, p.slabs, st))) return rc;
+  if (a->dwo && (rc = wgrad(dx2, a->attn_o, a->dwo, rows, D, D, dt, slabs, p.slabs, wst))) return rc;
   if ((rc = xp_attn_bwd2(a->qkv, 3 * D, a->attn_o, dattn, D, a->stats, a->pad_mask, dqkv, d.q_scale, d.attn_mode, d.B, d.heads,
                          d.S, d.M, d.N, d.L, dt, attn_ws, p.attn, (a->dbqkv && p.cs_qkv_fused) ? cs_qkv : nullptr, st))) return rc;
+  if ((rc = mark(3))) return rc;                                              // dqkv is ready for dWqkv
   g = gemm_desc(dqkv, a->Wqkv, dh1, rows, D, 3 * D, dt);                      // dh1 = dqkv . Wqkv
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
-  if (a->dwqkv && (rc = wgrad(dqkv, a->h1, a->dwqkv, rows, 3 * D, D, dt, slabs, p.slabs, st))) return rc;
+  if (a->dwqkv && (rc = wgrad(dqkv, a->h1, a->dwqkv, rows, 3 * D, D, dt, slabs, p.slabs, wst))) return rc;
   if (a->dbqkv) {
     if (!p.cs_qkv_fused && (rc = xp_colsum_partials(dqkv, rows, 3 * D, 3 * D, dt, cs_qkv, p.cs_qkv, st))) return rc;
     df.add(cs_qkv, a->dbqkv, 3 * D, (int)p.cs_qkv_rows, (int)(3 * D));
@@ -239,6 +289,12 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
   if (df.n) {
     XP_REQUIRE(xp_reduce_rows_batch_workspace_bytes(df.segs, df.n) <= p.red, "xp_encoder_layer_bwd: reduce scratch too small");
     if ((rc = xp_reduce_rows_batch(df.segs, df.n, red_ws, p.red, st))) return rc;
+  }
+  if (wsd) {      // join: the weight gradients (and every workspace the side stream read) belong to the main stream again
+    if (hipEventRecord(wsd->done, wsd->side) != hipSuccess || hipStreamWaitEvent(mst, wsd->done, 0) != hipSuccess) {
+      xp_set_error("xp_encoder_layer_bwd: joining the weight-gradient stream failed");
+      return XP_ERR_LAUNCH;
+    }
   }
   return XP_OK;
 }

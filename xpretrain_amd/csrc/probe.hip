@@ -111,6 +111,26 @@ extern "C" int xp_probe_stream_copy(void* dst, const void* src, int64_t nbytes, 
   return XP_OK;
 }
 
+// The same copy with the resource footprint of RCCL's gfx950 collective kernel (rcclGenericKernel<...> in the librccl.so this image
+// ships, read with llvm-readelf --notes from its unbundled gfx950 code object: 256 threads, 261-280 VGPRs + 17-32 AGPRs, 19,744 B of
+// LDS, 352 B of scratch).  More than 256 registers per lane means ONE wave per SIMD: such a workgroup needs four SIMDs with their
+// whole register file free, i.e. it cannot share a CU with a 256x256-GEMM workgroup (2 waves x ~244 registers per SIMD) -- it only
+// runs on CUs no GEMM workgroup occupies, and holds them for as long as the collective lasts.
+__global__ __launch_bounds__(256) void probe_stream_copy_fat_kernel(u32x4* dst, const u32x4* src, long n16, int iters) {
+  __shared__ unsigned pad[19744 / 4];
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");                      // vgpr_count 256
+  asm volatile("v_accvgpr_write_b32 a31, 0" ::: "a31");              // + 32 AGPRs -> 288 registers per lane: one wave per SIMD
+  if (threadIdx.x == 0) pad[blockIdx.x % (19744 / 4)] = 0;           // (keeps the LDS allocation)
+  for (int it = 0; it < iters; ++it)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int xp_probe_stream_copy_fat(void* dst, const void* src, int64_t nbytes, int32_t blocks, int32_t iters, void* stream) {
+  XP_REQUIRE(dst && src && nbytes >= 16 && blocks > 0 && iters > 0, "xp_probe_stream_copy_fat: bad arguments");
+  probe_stream_copy_fat_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((u32x4*)dst, (const u32x4*)src, nbytes / 16, iters);
+  XP_CHECK_LAUNCH("xp_probe_stream_copy_fat");
+  return XP_OK;
+}
+
 extern "C" int xp_probe_pk_f32(void* err, int32_t iters, int32_t blocks, uint32_t seed, void* stream) {
   probe_pk_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((unsigned*)err, iters, seed);
   XP_CHECK_LAUNCH("xp_probe_pk_f32");

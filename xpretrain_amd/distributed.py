@@ -40,6 +40,24 @@ def init_from_env(backend: Optional[str] = None) -> int:
     return local_rank
 
 
+def reserve_cus_for_collectives(n_channels: Optional[int] = None) -> int:
+    """Tell the GEMM planning how many CUs RCCL's kernels take away beside the backward pass.  RCCL's gfx950 collective kernel
+    (rcclGenericKernel in the librccl.so this image ships: 256 threads, 261-280 VGPRs + 17-32 AGPRs, 19.7 KB LDS -- llvm-readelf on
+    its unbundled code object) runs ONE wave per SIMD, so a channel's workgroup owns a CU for as long as a bucket all-reduce lasts
+    and cannot share it with a 256x256-GEMM workgroup.  With the default budget of 256 CUs a 252-workgroup dW launch would spill 12
+    tiles into a second round.  ``n_channels`` defaults to $NCCL_MAX_NCHANNELS (bench.py sets it for its ranks), else 16.  Returns
+    the budget set.  No-op in a 1-rank run."""
+    if world_size() == 1:
+        return 256
+    if n_channels is None:
+        n_channels = int(os.environ.get("NCCL_MAX_NCHANNELS", "16"))
+    budget = max(64, 256 - max(0, int(n_channels)))
+    if torch.cuda.is_available():
+        from . import functional as XF
+        XF.set_cu_budget(budget)
+    return budget
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

@@ -176,6 +176,15 @@ _ES = {torch.bfloat16: 2, torch.float32: 4}
 _PLANS = {}
 
 
+def set_cu_budget(cus: int) -> None:
+    """CUs the split-K planning of the weight-gradient GEMMs may fill (xp_set_cu_budget; 256 = the whole MI355X).  A data-parallel
+    run lowers it by the workgroups its collectives keep resident beside the backward pass (distributed.reserve_cus_for_collectives).
+    The memoised split factors and layer plans (workspace sizes depend on the split) are dropped."""
+    L.check(L.lib().xp_set_cu_budget(int(cus)), "xp_set_cu_budget")
+    _SPLITS.clear()
+    _PLANS.clear()
+
+
 def _a256(n: int) -> int:
     return (n + 255) & ~255
 
