@@ -17,6 +17,8 @@ from xpretrain_amd.modeling import VidCLIP  # noqa: E402
 from xpretrain_amd.optimization import NCELearnableTempLoss, AdamW, build_e2e_optimizer_w_lr_mul  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["thin", "fat"]                  # which aggressors
+counts = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [8, 16, 32, 64]    # workgroups per aggressor
 torch.manual_seed(1234)
 dev = torch.device("cuda", 0)
 model = VidCLIP(Args(O.vit_b_config(16, 224))).to(dev).train()
@@ -67,8 +69,11 @@ print(f"step alone: {base:.3f} ms")
 # kernel with the resources of RCCL's gfx950 collective kernel (csrc/probe.hip: 288 registers per lane = one wave per SIMD, 19,744 B
 # LDS) -- it cannot share a CU with a 256x256-GEMM workgroup, so its workgroups take whole CUs away from the GEMMs for as long as
 # the copy lasts, which is what a bucket all-reduce beside the backward pass does.
+print(f"CU budget of the split-K planning: {L.lib().xp_get_cu_budget()} (XPRETRAIN_CU_BUDGET / distributed.reserve_cus_for_collectives)")
 for fn, label in (("xp_probe_stream_copy", "thin"), ("xp_probe_stream_copy_fat", "rccl footprint")):
-    for blocks in (8, 16, 32, 64):
+    if ("thin" if label == "thin" else "fat") not in kinds:
+        continue
+    for blocks in counts:
         def alone():
             L.check(getattr(L.lib(), fn)(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, blocks, 1,
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "copy")

@@ -556,18 +556,30 @@ __global__ __launch_bounds__(F3THR, 2) void attn_fwd3_kernel(AP p) {
   }
 }
 
-// merge the per-frame partials of the proxy query rows: grid = B*H*M, 64 lanes = d
-__global__ void attn_fwd_merge_kernel(AP p) {
-  const int d = threadIdx.x;
+// merge the per-frame partials of the proxy query rows: grid = B*H*M, 4 waves x 64 lanes (lane = d).  Every wave finds the global
+// row maximum itself (lane n loads frame n's maximum: one load round), then wave w combines frames n = w, w + 4, ... (independent
+// loads, no serial chain over the frames) and the four partial sums are added in wave order through LDS (fixed order).
+__global__ __launch_bounds__(256) void attn_fwd_merge_kernel(AP p) {
+  __shared__ float red[4][DH + 1];
+  const int d = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int mrow = blockIdx.x % p.M, bh = blockIdx.x / p.M, h = bh % p.H, b = bh / p.H;
+  const float* base = p.ws0 + ((int64_t)bh * p.N * p.M + mrow) * PART;      // frame n: base + n * M * PART
+  const int64_t fstride = (int64_t)p.M * PART;
   float mx = -INFINITY;
-  for (int n = 0; n < p.N; ++n) mx = fmaxf(mx, p.ws0[(((int64_t)bh * p.N + n) * p.M + mrow) * PART]);
+  for (int n0 = 0; n0 < p.N; n0 += 64) mx = fmaxf(mx, (n0 + d < p.N) ? base[(n0 + d) * fstride] : -INFINITY);
+  mx = wave_max(mx);
   float l = 0.f, acc = 0.f;
-  for (int n = 0; n < p.N; ++n) {
-    const float* part = p.ws0 + (((int64_t)bh * p.N + n) * p.M + mrow) * PART;
-    const float w = __expf(part[0] - mx);
-    l += part[1] * w; acc += part[2 + d] * w;
+  for (int n = w; n < p.N; n += 4) {
+    const float* part = base + n * fstride;
+    const float wgt = __expf(part[0] - mx);
+    l += part[1] * wgt; acc += part[2 + d] * wgt;
   }
+  red[w][d] = acc;
+  if (d == 0) red[w][DH] = l;
+  __syncthreads();
+  if (w != 0) return;
+  acc = ((red[0][d] + red[1][d]) + red[2][d]) + red[3][d];
+  l = ((red[0][DH] + red[1][DH]) + red[2][DH]) + red[3][DH];
   const int64_t tok = (int64_t)b * p.S + mrow;
   p.out[tok * p.ldo + h * DH + d] = (bf16_t)(acc / l);
   if (d == 0) { float* st = p.stats + (((int64_t)b * p.H + h) * p.S + mrow) * 2; st[0] = mx; st[1] = __logf(l); }
@@ -929,17 +941,25 @@ __global__ __launch_bounds__(FTHR, 4) void attn_bwd_dq_kernel(AP p) {
   }
 }
 
-// proxy tokens: sum the per-frame partials.  grid = B*H*M, 64 lanes = d
-__global__ void attn_bwd_proxy_reduce_kernel(AP p) {
-  const int d = threadIdx.x;
+// proxy tokens: sum the per-frame partials.  grid = B*H*M, 4 waves x 64 lanes (lane = d); wave w sums frames n = w, w + 4, ...,
+// the four partial sums are added in wave order through LDS (fixed order)
+__global__ __launch_bounds__(256) void attn_bwd_proxy_reduce_kernel(AP p) {
+  __shared__ float red[4][3][DH];
+  const int d = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int mrow = blockIdx.x % p.M, bh = blockIdx.x / p.M, h = bh % p.H, b = bh / p.H;
   float q = 0.f, k = 0.f, v = 0.f;
-  for (int n = 0; n < p.N; ++n) {
+  for (int n = w; n < p.N; n += 4) {
     const int64_t pi = ((int64_t)bh * p.N + n) * p.M + mrow;
     q += p.ws1[pi * DH + d];
     k += p.ws2[pi * 2 * DH + d];
     v += p.ws2[pi * 2 * DH + DH + d];
   }
+  red[w][0][d] = q; red[w][1][d] = k; red[w][2][d] = v;
+  __syncthreads();
+  if (w != 0) return;
+  q = ((red[0][0][d] + red[1][0][d]) + red[2][0][d]) + red[3][0][d];
+  k = ((red[0][1][d] + red[1][1][d]) + red[2][1][d]) + red[3][1][d];
+  v = ((red[0][2][d] + red[1][2][d]) + red[2][2][d]) + red[3][2][d];
   bf16_t* base = p.dqkv + ((int64_t)b * p.S + mrow) * p.ldqkv + h * DH + d;
   const bf16_t qb = (bf16_t)(q * p.q_scale), kb = (bf16_t)k, vb = (bf16_t)v;
   base[0] = qb;
@@ -1019,7 +1039,7 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   }
   XP_CHECK_LAUNCH("xp_attn_fwd");
   if (mode == XP_ATTN_PROXY) {
-    attn_fwd_merge_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
+    attn_fwd_merge_kernel<<<(unsigned)(B * H * M), 256, 0, st>>>(p);
     XP_CHECK_LAUNCH("xp_attn_fwd(merge)");
   }
   return XP_OK;
@@ -1070,7 +1090,7 @@ extern "C" int xp_attn_bwd2(const void* qkv, int64_t ldqkv, const void* out, con
   attn_bwd_dkv_kernel<<<grid, FTHR, 0, st>>>(p);
   XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
   if (mode == XP_ATTN_PROXY) {
-    attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 64, 0, st>>>(p);
+    attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 256, 0, st>>>(p);
     XP_CHECK_LAUNCH("xp_attn_bwd(proxy reduce)");
   }
   return XP_OK;
