@@ -438,13 +438,13 @@ def main():
             "vit_forward_note": "vit_forward_ms = inference mode (torch.no_grad: no pre-activation kept); the fraction of peak is "
                                 "quoted on vit_forward_train_mode_ms, the kernels the benchmark step runs",
             # dominant forward kernel; algorithmic bytes = A + W + two bf16 outputs
-            "roofline": {"bound": "mfma", "kernel": f"gemm256s_kernel<NT> (256x256 tiles, staged epilogue: the kernel the training step runs) fc1 +bias+quick_gelu [{rows}x768]x[768x3072]",
+            "roofline": {"bound": "mfma", "kernel": f"gemm256_kernel<NT> (256x256 tiles, the kernel the training step runs) fc1 +bias+quick_gelu, two bf16 outputs [{rows}x768]x[768x3072]",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(k_ms, 4),
                          "traffic": tr_f, "traffic_unit": "bytes/launch", "traffic_source": note_f,
                          "algorithmic_bytes": (rows * 768 + 3072 * 768 + 2 * rows * 3072) * 2},
             # dominant backward kernel (incl. its split-K reduce); algorithmic bytes = dpre + h2 + fp32 dW
-            "roofline_bwd": {"bound": "mfma", "kernel": f"gemm256s_kernel<SS> dW1 = dpre^T.h2 [3072x{rows}]x[{rows}x768] split-K + reduce",
+            "roofline_bwd": {"bound": "mfma", "kernel": f"gemm256_kernel<SS> dW1 = dpre^T.h2 [3072x{rows}]x[{rows}x768] split-K + reduce",
                              "achieved": round(b_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(b_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(b_ms, 4),
                              "traffic": tr_b, "traffic_unit": "bytes/launch (GEMM kernel only)", "traffic_source": note_b,

@@ -77,13 +77,8 @@ typedef struct XpGemmDesc {
    * Only where xp_gemm_colsum_rows() > 0 (large bf16 problems, EPI_NONE / EPI_GELU_BWD); finish with
    * xp_reduce_rows_batch. */
   float* colsum_partials;
-  /* Which kernels of the 256-wide family serve the call (no effect elsewhere).  0: library default = what is fastest INSIDE the
-   * training step: 256-row tiles, LDS-staged epilogue (csrc/gemm256s.hip).  224: latency-first -- the direct-epilogue / persistent
-   * kernels (csrc/gemm256.hip) with 224-row tiles where they fill the last round of CUs better; a forward-only pass is 2-4 % faster
-   * with them, so the inference forward (retrieval, tasks/run_video_retrieval.py:123-203) asks for it.  256: those kernels at 256-row
-   * tiles (tests, A/B).  On MI355X the GEMMs run against the power limit, and the choice was made by timing whole training steps
-   * of both kernel sets on one box: isolated launches rank them the other way round. */
-  int32_t tile_rows_hint;
+  /* reserved (round 3 selected a second kernel set of the 256-wide family here; since round 4 there is one): ignored */
+  int32_t reserved0;
   int32_t side_M;
   /* optional, EPI_BIAS_RESID: fp32 "side rows" of the residual stream.  Output rows m with m % side_S < side_M (the video tower's
    * proxy tokens: rows [0, M) of every sample of S tokens, CLIP_ViP.py:187-197) take their residual operand from
@@ -108,10 +103,9 @@ int32_t xp_get_cu_budget(void);
 /* number of partial rows xp_gemm writes to desc->colsum_partials, or 0 if the fused column sums are not available
  * for this problem (desc->colsum_partials itself is ignored here) */
 int64_t xp_gemm_colsum_rows(const XpGemmDesc* desc);
-/* Output-tile height (rows) of the kernel family xp_gemm will run `desc` with: 256 / 224 for the 256-wide ping-pong family
- * (the height is chosen per problem so that the tile count fills whole rounds of the 256 CUs: at CLIP-ViP's 18848 token
- * rows, modeling/CLIP_ViP.py:341-343,379,393-395, 85 x {3,9,12} tiles of 224 rows instead of 74 x {3,9,12} of 256), 128 for
- * the 128x128 family.  desc->split_k is honoured; the data pointers are ignored. */
+/* Output-tile height (rows) of the kernel family xp_gemm will run `desc` with: 256 for the 256-wide ping-pong family (the four
+ * Linear layers of CLIPEncoderLayer at video-tower sizes, modeling/CLIP_ViP.py:341-343,379,393-395), 128 for the 128x128 family.
+ * desc->split_k is honoured; the data pointers are ignored. */
 int32_t xp_gemm_tile_rows(const XpGemmDesc* desc);
 
 /* out[i] (+)= sum_z slabs[z*n + i], fp32; accumulate != 0 adds into out (gradient accumulation). */

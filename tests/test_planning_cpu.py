@@ -7,7 +7,7 @@ import pytest
 from xpretrain_amd import _lib as L
 
 
-def _desc(M, N, K, *, a_ks=True, b_ks=True, dtype=L.XP_BF16, out=L.XP_F32, epi=L.EPI_NONE, split=1, hint=0):
+def _desc(M, N, K, *, a_ks=True, b_ks=True, dtype=L.XP_BF16, out=L.XP_F32, epi=L.EPI_NONE, split=1):
     d = L.XpGemmDesc()
     d.M, d.N, d.K = M, N, K
     d.lda = M if a_ks else K
@@ -15,7 +15,6 @@ def _desc(M, N, K, *, a_ks=True, b_ks=True, dtype=L.XP_BF16, out=L.XP_F32, epi=L
     d.ldc = N
     d.a_kstrided, d.b_kstrided = int(a_ks), int(b_ks)
     d.in_dtype, d.out_dtype, d.epilogue, d.split_k = dtype, out, epi, split
-    d.tile_rows_hint = hint
     return d
 
 
@@ -47,8 +46,6 @@ def test_fused_colsum_availability():
     big = dict(a_ks=False, b_ks=True, out=L.XP_BF16)
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_GELU_BWD, **big))) == 2 * 74      # 74 tiles of 256 rows (default height)
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, **big))) == 2 * 74
-    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, hint=224, **big))) == 2 * 85
-    assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 768, 768, epi=L.EPI_NONE, hint=256, **big))) == 2 * 74   # both kernel sets: one row per wave row
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(256, 2048, 512, epi=L.EPI_GELU_BWD, **big))) == 0          # text tower: 128 family
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, epi=L.EPI_BIAS, **big))) == 0            # other epilogue
     assert lib.xp_gemm_colsum_rows(C.byref(_desc(18848, 3072, 768, a_ks=False, b_ks=True, out=L.XP_F32))) == 0
@@ -57,21 +54,33 @@ def test_fused_colsum_availability():
 
 
 def test_tile_height_planning():
-    """xp_gemm_tile_rows: with tile_rows_hint = 224, 224-row tiles where 256-row tiles would leave an eighth of the last round of
-    CUs idle (18848 and 50208 token rows of the BASELINE shapes); without the hint 256; 256 for weight gradients and exact
-    multiples, 128 = the 128x128 family."""
+    """xp_gemm_tile_rows: 256 for everything the 256-wide family serves (video-tower activations and weight gradients), 128 = the
+    128x128 family (text tower, fp32 inputs)."""
     lib = L.lib()
     act = dict(a_ks=False, b_ks=False, out=L.XP_BF16)
     for N in (768, 2304, 3072):
-        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, hint=224, **act))) == 224
-        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, **act))) == 256             # default: the staged-epilogue kernels
-        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, hint=256, **act))) == 256   # the direct-epilogue kernels at 256 rows
-    assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, 768, 3072, a_ks=False, b_ks=True, out=L.XP_BF16, hint=224))) == 224
-    assert lib.xp_gemm_tile_rows(C.byref(_desc(50208, 768, 768, hint=224, **act))) == 224
+        assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, N, 768, **act))) == 256
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, 768, 3072, a_ks=False, b_ks=True, out=L.XP_BF16))) == 256
+    assert lib.xp_gemm_tile_rows(C.byref(_desc(50208, 768, 768, **act))) == 256
     assert lib.xp_gemm_tile_rows(C.byref(_desc(3072, 768, 18848, split=7))) == 256        # dW1: 36 tiles x 7 slabs
-    assert lib.xp_gemm_tile_rows(C.byref(_desc(16384, 1024, 512, hint=224, **act))) == 256
     assert lib.xp_gemm_tile_rows(C.byref(_desc(256, 2048, 512, **act))) == 128            # text tower
     assert lib.xp_gemm_tile_rows(C.byref(_desc(18848, 768, 768, dtype=L.XP_F32, a_ks=False, b_ks=False))) == 128
+
+
+def test_cu_budget_shrinks_the_split():
+    """xp_set_cu_budget: a data-parallel run reserves the CUs its collective kernels own (distributed.reserve_cus_for_collectives);
+    the dW launches must then fit the remaining CUs in one round."""
+    lib = L.lib()
+    try:
+        for budget, expect in ((256, (7, 9, 27)), (240, (6, 8, 25)), (224, (6, 8, 23))):      # (whole 64-token k-steps per slab)
+            assert lib.xp_set_cu_budget(budget) == 0 and lib.xp_get_cu_budget() == budget
+            got = tuple(lib.xp_gemm_auto_split(C.byref(_desc(M, N, 18848))) for M, N in ((3072, 768), (2304, 768), (768, 768)))
+            tiles = (36, 27, 9)
+            assert all(s * t <= budget for s, t in zip(got, tiles)), (budget, got)
+            assert got == expect, (budget, got)
+        assert lib.xp_set_cu_budget(32) != 0           # out of range: refused
+    finally:
+        lib.xp_set_cu_budget(256)
 
 
 def test_partial_row_counts_and_workspaces():

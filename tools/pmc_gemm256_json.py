@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["xpretrain_amd/csrc/gemm256.hip", "xpretrain_amd/csrc/gemm256s.hip", "xpretrain_amd/csrc/gemm_common.h", "xpretrain_amd/csrc/common.h",
+SOURCES = ["xpretrain_amd/csrc/gemm256.hip", "xpretrain_amd/csrc/gemm_common.h", "xpretrain_amd/csrc/common.h",
            "xpretrain_amd/csrc/gemm.hip"]
 
 
@@ -22,10 +22,7 @@ def source_stamp(root=ROOT):
 
 
 # grid sizes (threads) of the probe's launches: tiles * 512 threads
-# the probe runs the training-shaped calls: they take the staged-epilogue kernels of the family (gemm256s.hip) by default
-VARIANT = {"gemm256s_kernel<false, false": "NT_fc1_fwd", "gemm256s_kernel<false, true": "NS_dpre_dx", "gemm256s_kernel<true, true": "SS_dw1",
-           "gemm256_persist_kernel<": "NT_fc1_fwd", "gemm256_kernel<false, false": "NT_fc1_fwd", "gemm256_kernel<false, true": "NS_dpre_dx",
-           "gemm256_kernel<true, true": "SS_dw1"}
+VARIANT = {"gemm256_kernel<false, false": "NT_fc1_fwd", "gemm256_kernel<false, true": "NS_dpre_dx", "gemm256_kernel<true, true": "SS_dw1"}
 
 if __name__ == "__main__":
     tag, d, out = sys.argv[1:4]

@@ -39,7 +39,7 @@ class XpGemmDesc(C.Structure):
         ("aux", vp), ("ldaux", i64),
         ("tab1", vp), ("tab2", vp), ("tab_L", i64),
         ("colsum_partials", vp),
-        ("tile_rows_hint", i32), ("side_M", i32),
+        ("reserved0", i32), ("side_M", i32),
         ("resid_side", vp), ("out_side", vp), ("side_S", i64),
     ]
 

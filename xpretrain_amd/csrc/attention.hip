@@ -1024,14 +1024,29 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   p.ws2 = (float*)g_attn_trace;
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)(B * H * N);
-  static const int fwd3 = getenv("XPRETRAIN_ATTN_FWD3") ? atoi(getenv("XPRETRAIN_ATTN_FWD3")) : 1;     // A/B switch
-  if (fwd3 && mode == XP_ATTN_PROXY && p.R <= FG && !pad_mask) {
-    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
-                                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static std::once_flag configured;
-    std::call_once(configured, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS);
-    });
+  static const int fwd3 = getenv("XPRETRAIN_ATTN_FWD3") ? atoi(getenv("XPRETRAIN_ATTN_FWD3")) : 1;     // debug switch: 0 = always the 7-wave kernel
+  // the persistent kernel: proxy problems that fit one LDS group, no padding mask, at most 16 proxy rows (its proxy x proxy mask
+  // lives in query tile 0 / key sub-tile 0 only), and a device that grants the 104 KiB dynamic-LDS opt-in (configured per device)
+  bool use3 = fwd3 && mode == XP_ATTN_PROXY && p.R <= FG && p.M <= 16 && !pad_mask;
+  int ncu = 256;
+  if (use3) {
+    static std::mutex mu;
+    static int configured[64] = {0};                  // per device -- 0: not yet, > 0: CU count, -1: refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) use3 = false;
+    else {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!configured[dev]) {
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            F3_LDS) == hipSuccess;
+        configured[dev] = ok ? (n > 0 ? n : 256) : -1;
+      }
+      if (configured[dev] < 0) use3 = false; else ncu = configured[dev];
+    }
+  }
+  if (use3) {
     const int fgrid = fwd3 > 1 ? fwd3 : ncu;              // (XPRETRAIN_ATTN_FWD3=<n>: grid size, for experiments)
     attn_fwd3_kernel<<<(unsigned)(p.nprob < fgrid ? p.nprob : fgrid), F3THR, F3_LDS, st>>>(p);
   } else {

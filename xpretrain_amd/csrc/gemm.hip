@@ -594,10 +594,6 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
              split, (long long)d->K, zsplits);
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   hipStream_t st = (hipStream_t)stream;
-  if (xp_gemm256s_selected(d) && xp_gemm256_wanted(d, split) && xp_gemm256s_try(d, kp, st)) {   // staged-epilogue kernels of the family
-    XP_CHECK_LAUNCH("xp_gemm(256s)");
-    return XP_OK;
-  }
   if (xp_gemm256_try(d, kp, st)) {     // large dense problems: 256x256 ping-pong family
     XP_CHECK_LAUNCH("xp_gemm(256)");
     return XP_OK;
@@ -630,7 +626,7 @@ extern "C" int32_t xp_gemm_tile_rows(const XpGemmDesc* d) {
   const int split = d->split_k > 1 ? d->split_k : 1;
   const int64_t k_per = cdiv(cdiv(d->K, split), 64) * 64;
   if (xp_gemm256_wanted(d, split) && cdiv(d->K - (int64_t)(split - 1) * k_per, 64) >= 2 && (split == 1 || cdiv(d->K, k_per) == split))
-    return 32 * (4 + xp_gemm256_mt1(d, split));
+    return 256;
   return BM;
 }
 

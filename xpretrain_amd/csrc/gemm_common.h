@@ -299,10 +299,5 @@ __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int gr
 bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st);
 bool xp_gemm256_legal(const XpGemmDesc* d);
 bool xp_gemm256_wanted(const XpGemmDesc* d, int split);
-int xp_gemm256_mt1(const XpGemmDesc* d, int split);
 int64_t xp_gemm256_colsum_rows(const XpGemmDesc* d);
-// gemm256s.hip: the same family with the LDS-staged epilogue (256-row tiles only), preferred inside the training step
-#define XP_GEMM256_STAGED_DEFAULT 7
-bool xp_gemm256s_selected(const XpGemmDesc* d);
-bool xp_gemm256s_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st);
 bool xp_gemm_fast_epi_ok(const XpGemmDesc* d);

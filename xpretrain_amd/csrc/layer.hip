@@ -116,7 +116,6 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
              a->rstd1 && a->mean2 && a->rstd2 && a->stats, "xp_encoder_layer_fwd: null pointer");
   const int64_t rows = d.rows, D = d.D, Dff = d.Dff;
   const int dt = d.dtype;
-  const int hint = a->pre ? 0 : 224;       // forward-only pass (no pre-activation kept): latency first -> 224-row GEMM tiles
   // fp32 side rows of the residual stream (the M proxy tokens of every sample): x rows in side_in, x2 rows in the workspace,
   // x3 rows in side_out
   const bool sided = a->side_in != nullptr;
@@ -133,24 +132,24 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
                                   a->side_in, nullptr, sS, sM, sM, st))) return rc;
   // qkv = (h1 Wqkv^T + b), q columns scaled by dh^-0.5 (:341)
   XpGemmDesc g = gemm_desc(a->h1, a->Wqkv, a->qkv, rows, 3 * D, D, dt);
-  g.epilogue = XP_EPI_BIAS_QSCALE; g.bias = a->bqkv; g.scale = d.q_scale; g.scale_cols = D; g.tile_rows_hint = hint;
+  g.epilogue = XP_EPI_BIAS_QSCALE; g.bias = a->bqkv; g.scale = d.q_scale; g.scale_cols = D;
   if ((rc = xp_gemm(&g, st))) return rc;
   if ((rc = xp_attn_fwd(a->qkv, 3 * D, a->attn_o, D, a->stats, a->pad_mask, d.attn_mode, d.B, d.heads, d.S, d.M, d.N, d.L, dt,
                         a->workspace, a->workspace_bytes, st))) return rc;
   // x2 = x + attn_o Wo^T + bo
   g = gemm_desc(a->attn_o, a->Wo, a->x2, rows, D, D, dt);
-  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->bo; g.resid = a->x; g.tile_rows_hint = hint;
+  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->bo; g.resid = a->x;
   if (sided) { g.resid_side = a->side_in; g.out_side = side_x2; g.side_S = sS; g.side_M = sM; }
   if ((rc = xp_gemm(&g, st))) return rc;
   if ((rc = xp_layernorm_fwd_side(a->x2, D, a->ln2_w, a->ln2_b, a->h2, D, a->mean2, a->rstd2, rows, D, d.ln_eps, dt,
                                   side_x2, nullptr, sS, sM, sM, st))) return rc;
   // pre = h2 W1^T + b1 ; act = quick_gelu(pre)
   g = gemm_desc(a->h2, a->W1, a->act, rows, Dff, D, dt);
-  g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre; g.tile_rows_hint = hint;
+  g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre;
   if ((rc = xp_gemm(&g, st))) return rc;
   // x3 = x2 + act W2^T + b2
   g = gemm_desc(a->act, a->W2, a->x3, rows, D, Dff, dt);
-  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->b2; g.resid = a->x2; g.tile_rows_hint = hint;
+  g.epilogue = XP_EPI_BIAS_RESID; g.bias = a->b2; g.resid = a->x2;
   if (sided) { g.resid_side = side_x2; g.out_side = a->side_out; g.side_S = sS; g.side_M = sM; }
   return xp_gemm(&g, st);
 }

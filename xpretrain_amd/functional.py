@@ -413,17 +413,16 @@ class EncoderLayerFn(torch.autograd.Function):
         side_x2 = None if side is None else torch.empty_like(side)
         side_out = None if side is None else torch.empty_like(side)
 
-        hint = 0 if training else 224       # forward-only pass: latency-first GEMM tiles (as csrc/layer.hip)
         lns = None if side is None else ((S, size[0], size[0]) if size is not None else (1, 1, 1))
         h1, mean1, rstd1 = H.layernorm_fwd(x, ln1_w, ln1_b, rows, D, x_side=side, side=lns)
-        qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D, tile_rows_hint=hint)
+        qkv = H.gemm(h1, Wqkv, rows, 3 * D, D, epilogue=L.EPI_BIAS_QSCALE, bias=bqkv, scale=q_scale, scale_cols=D)
         attn_o, stats = H.attn_fwd(qkv, B, S, heads, size=size, pad_mask=pad_mask)
-        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x, tile_rows_hint=hint,
+        x2 = H.gemm(attn_o, Wo, rows, D, D, epilogue=L.EPI_BIAS_RESID, bias=bo.detach(), resid=x,
                     resid_side=side, out_side=side_x2, side=sd)
         h2, mean2, rstd2 = H.layernorm_fwd(x2, ln2_w, ln2_b, rows, D, x_side=side_x2, side=lns)
         pre = torch.empty((rows, Dff), dtype=dt, device=x.device) if training else None
-        act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre, tile_rows_hint=hint)
-        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2, tile_rows_hint=hint,
+        act = H.gemm(h2, W1, rows, Dff, D, epilogue=L.EPI_BIAS_GELU, bias=b1.detach(), aux=pre)
+        x3 = H.gemm(act, W2, rows, D, Dff, epilogue=L.EPI_BIAS_RESID, bias=b2.detach(), resid=x2,
                     resid_side=side_x2, out_side=side_out, side=sd)
 
         if training:

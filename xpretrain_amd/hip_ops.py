@@ -60,7 +60,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
          a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
          scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
          a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None, colsum_name="gemm_colsum",
-         tile_rows_hint=0, resid_side=None, out_side=None, side=None):
+         resid_side=None, out_side=None, side=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc.
 
     ``colsum_defer`` (a DeferredReduce): also return the column sums of C (a bias gradient), as ``(C, colsum)``; the
@@ -93,7 +93,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     d.tab1 = 0 if tab1 is None else _chk(tab1, "tab1", torch.float32).data_ptr()
     d.tab2 = 0 if tab2 is None else _chk(tab2, "tab2", torch.float32).data_ptr()
     d.tab_L = tab_L
-    d.tile_rows_hint = tile_rows_hint
     if resid_side is not None or out_side is not None:       # fp32 side rows of the residual stream: side = (S, M)
         _chk(resid_side, "resid_side", torch.float32); _chk(out_side, "out_side", torch.float32)
         S_, M_ = side
