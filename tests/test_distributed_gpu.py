@@ -65,6 +65,28 @@ def test_one_rank_nccl_group_matches_plain_step():
         assert not XF.GRAD_SINKS
         return res, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
+    def dual_pass_grads(sinks):
+        """VidCLIP.forward's second (image, caption) pass applies every encoder layer TWICE in one graph (VidCLIP.py:70-79): with
+        gradient sinks on, only the first application of a layer may write the sink (functional._claim_sink) -- the gradients must
+        be g1 + g2 exactly as without sinks, not two aliases of the second write."""
+        import xpretrain_amd.functional as XF
+        from xpretrain_amd.optimization import NCELearnableTempLoss_vsc_fc
+        torch.manual_seed(5)
+        model = VidCLIP(_Args(cfgd, 2)).cuda().train()
+        reducer = D.GradBucketReducer(model.parameters(), bucket_mb=0.25, average=True,
+                                      layout_groups=XF.layer_grad_groups(model) if sinks else None)
+        video, ids, mask = batch
+        image = video[:, :1].contiguous()
+        cap_ids, cap_mask = ids.flip(0).contiguous().view(-1, 1, ids.shape[1]), mask.flip(0).contiguous().view(-1, 1, mask.shape[1])
+        out = model(video, ids, mask, image=image, caption_ids=cap_ids, caption_masks=cap_mask)
+        loss = NCELearnableTempLoss_vsc_fc()(out["vis_features"], out["text_features"], out["img_features"], out["cap_features"],
+                                             model.clipmodel.logit_scale)
+        loss.backward()
+        reducer.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        reducer.zero_grad(); reducer.remove()
+        return loss.detach().clone(), grads
+
     plain, sd0 = run(False)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", world_size=1, rank=0)
@@ -73,6 +95,8 @@ def test_one_rank_nccl_group_matches_plain_step():
         forced, sd1 = run(True)
         direct, sd2 = run(True, sinks=True)           # gradients written straight into the bucket storage
         wire16, sd3 = run(True, sinks=True, wire=torch.bfloat16)
+        dl0, dg0 = dual_pass_grads(False)
+        dl1, dg1 = dual_pass_grads(True)
     finally:
         D.FORCE_COLLECTIVES = False
         dist.destroy_process_group()
@@ -91,3 +115,7 @@ def test_one_rank_nccl_group_matches_plain_step():
     for it, ((l1, n1), (l3, n3)) in enumerate(zip(forced, wire16)):
         assert abs(l1.item() - l3.item()) <= (1e-5 if it == 0 else 1e-2) * max(1.0, abs(l1.item()))
         assert abs(n1.item() - n3.item()) <= 5e-2 * abs(n1.item())
+    # the dual pass with sinks: every gradient equals the no-sink run (a layer applied twice writes its sink once)
+    assert dl0.item() == dl1.item() and dg0.keys() == dg1.keys()
+    bad = [n for n in dg0 if not torch.allclose(dg0[n], dg1[n], rtol=1e-6, atol=1e-9)]
+    assert not bad, bad[:5]

@@ -332,3 +332,37 @@ def test_native_layer_calls_equal_the_op_by_op_path(dtype):
         assert (g0[n] is None) == (g1[n] is None), n
         if g0[n] is not None:
             assert torch.equal(g0[n], g1[n]), n
+
+
+def test_gradient_checkpointing_recomputes_bit_identically():
+    """CLIPEncoder.gradient_checkpointing (reference CLIP_ViP.py:626,675-690): with it the saved-activation arenas are dropped after the
+    forward and every layer is re-run when its backward starts -- same kernels, same inputs: features, loss and all gradients are
+    bit-identical to the plain run, and the peak memory of the step is lower."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    torch.manual_seed(7)
+    cfgd = O.hf_config_dict(128, 2, 4, 256, 16, 32, 128, 2, 3, 256, 120, 16, 64)
+    model = VidCLIP(_Args(cfgd, 3)).cuda().train()
+    video, ids, mask = (t.cuda() for t in O.synthetic_inputs(4, 3, 32, 12, vocab=120))
+
+    def run(ckpt):
+        if ckpt:
+            model.clipmodel.gradient_checkpointing_enable()
+        else:
+            model.clipmodel.gradient_checkpointing_disable()
+        assert all(m.gradient_checkpointing == ckpt for m in model.modules() if hasattr(m, "gradient_checkpointing"))
+        for p in model.parameters():
+            p.grad = None
+        torch.cuda.reset_peak_memory_stats()
+        out = model(video, ids, mask)
+        loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (out["vis_features"].detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()},
+                torch.cuda.max_memory_allocated())
+    v0, l0, g0, m0 = run(False)
+    v1, l1, g1, m1 = run(True)
+    assert torch.equal(v0, v1) and torch.equal(l0, l1)
+    bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not bad, bad[:5]
+    assert m1 < m0, (m0, m1)

@@ -230,15 +230,29 @@ class CLIPEncoder(nn.Module):
         self.layers = nn.ModuleList([CLIPEncoderLayer(config) for _ in range(config.num_hidden_layers)])
         self.gradient_checkpointing = False
 
-    def forward(self, x, B, S, inputs_size=None, pad_mask=None, collect=None, side=None):
-        """``side``: the proxy rows of ``x`` in fp32 (video tower, bf16 compute: XF.PROXY_SIDE); returns ``(x, side)`` then."""
+    def forward(self, x, B, S, inputs_size=None, pad_mask=None, collect=None, side=None, collect_side=None):
+        """``side``: the proxy rows of ``x`` in fp32 (video tower, bf16 compute: XF.PROXY_SIDE); returns ``(x, side)`` then.
+        ``collect`` / ``collect_side``: lists that receive every layer output (compute dtype, as ``last_hidden_state``) and its
+        fp32 side rows (``output_hidden_states``)."""
+        ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
         for layer in self.layers:
-            if side is None:
+            if ckpt:
+                # reference CLIP_ViP.py:675-690 (torch.utils.checkpoint around every encoder layer): the layer's saved-activation
+                # arena is dropped after the forward and rebuilt by re-running the layer when its backward starts -- the same
+                # kernels on the same inputs, so the gradients are bit-identical to the non-checkpointed run
+                from torch.utils.checkpoint import checkpoint
+                if side is None:
+                    x = checkpoint(lambda t, _l=layer: _l(t, B, S, inputs_size, pad_mask), x, use_reentrant=False)
+                else:
+                    x, side = checkpoint(lambda t, sd, _l=layer: _l(t, B, S, inputs_size, pad_mask, sd), x, side, use_reentrant=False)
+            elif side is None:
                 x = layer(x, B, S, inputs_size, pad_mask)
             else:
                 x, side = layer(x, B, S, inputs_size, pad_mask, side)
             if collect is not None:
-                collect.append(XF.with_side_rows(x, side, B, S))
+                collect.append(x)
+                if collect_side is not None and side is not None:
+                    collect_side.append(side)
         return x if side is None else (x, side)
 
 
@@ -272,13 +286,13 @@ class CLIPTextTransformer(nn.Module):
             # side-row mechanism as the video tower's proxy tokens, with every row a side row)
             emb = self.embeddings
             side = XF.H.text_embed_fwd(input_ids, emb.token_embedding.weight.detach(), emb.position_embedding.weight.detach(), torch.float32)
-            hs = [XF.with_side_rows(x, side, B, Lt)] if output_hidden_states else None
-            x, side = self.encoder(x, B, Lt, None, pad, hs, side)
+            hs, hside = ([x], [side]) if output_hidden_states else (None, None)
+            x, side = self.encoder(x, B, Lt, None, pad, hs, side, hside)
             pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, idx, B, Lt), ln.weight, ln.bias,
                                           XF.H.gather_rows(side, idx, B, Lt, D), (1, 1, 1))
             last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias, side, (1, 1, 1)).view(B, Lt, D))
         else:
-            hs = [x] if output_hidden_states else None
+            hs, hside = ([x] if output_hidden_states else None), None
             x = self.encoder(x, B, Lt, None, pad, hs)
             # LayerNorm is row-wise, so pooling the EOT rows first and normalising only those is identical to
             # final_layer_norm followed by the gather (:772-776); the full normalised sequence is only produced
@@ -287,6 +301,7 @@ class CLIPTextTransformer(nn.Module):
             last = _Lazy(lambda: XF.LayerNormFn.apply(x, ln.weight, ln.bias).view(B, Lt, D))      # (:772) resolved on access
         out = BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled,
                                          hidden_states=None if hs is None else tuple(h.view(B, Lt, D) for h in hs),
+                                         hidden_side_rows=None if hside is None else tuple(h.view(B, Lt, D) for h in hside),
                                          attentions=None)
         return out if return_dict is None or return_dict else out.to_tuple()
 
@@ -318,18 +333,19 @@ class CLIPVisionTransformer(nn.Module):
             emb = self.embeddings
             side = XF.proxy_side_rows(emb.class_embedding, emb.added_cls, emb.position_embedding.weight, B, M)
             x, side = XF.LayerNormFn.apply(x, self.pre_layrnorm.weight, self.pre_layrnorm.bias, side, (S, M, M), True)
-            hs = [XF.with_side_rows(x, side, B, S)] if output_hidden_states else None
-            x, side = self.encoder(x, B, S, size, None, hs, side)
+            hs, hside = ([x], [side]) if output_hidden_states else (None, None)
+            x, side = self.encoder(x, B, S, size, None, hs, side, hside)
             pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
                                           self.post_layernorm.bias, side, (1, 1, M))
         else:
             x = XF.LayerNormFn.apply(x, self.pre_layrnorm.weight, self.pre_layrnorm.bias)
-            hs = [x] if output_hidden_states else None
+            hs, hside = ([x] if output_hidden_states else None), None
             x = self.encoder(x, B, S, size, None, hs)
             pooled = XF.LayerNormFn.apply(XF.GatherRowsFn.apply(x, None, B, S), self.post_layernorm.weight,
                                           self.post_layernorm.bias)
         out = BaseModelOutputWithPooling(last_hidden_state=x.view(B, S, D), pooler_output=pooled,
                                          hidden_states=None if hs is None else tuple(h.view(B, S, D) for h in hs),
+                                         hidden_side_rows=None if hside is None else tuple(h.view(B, M, D) for h in hside),
                                          attentions=None)
         return out if return_dict is None or return_dict else out.to_tuple()
 
@@ -338,9 +354,26 @@ class CLIPVisionTransformer(nn.Module):
 class CLIPPreTrainedModel(nn.Module):
     """Weight init of the reference's ``_init_weights`` (CLIP_ViP.py:481-522) + local checkpoint loading."""
 
+    supports_gradient_checkpointing = True          # reference CLIP_ViP.py:478
+
     def __init__(self, config):
         super().__init__()
         self.config = config
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        """reference CLIP_ViP.py:524-526"""
+        if isinstance(module, CLIPEncoder):
+            module.gradient_checkpointing = value
+
+    def gradient_checkpointing_enable(self):
+        """transformers.PreTrainedModel.gradient_checkpointing_enable: every CLIPEncoder below this module recomputes its layers'
+        activations in the backward pass (CLIP_ViP.py:675-690)"""
+        for m in self.modules():
+            self._set_gradient_checkpointing(m, True)
+
+    def gradient_checkpointing_disable(self):
+        for m in self.modules():
+            self._set_gradient_checkpointing(m, False)
 
     def _init_weights(self, module):
         factor = getattr(self.config, "initializer_factor", 1.0)
