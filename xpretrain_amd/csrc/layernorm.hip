@@ -6,6 +6,7 @@
 // the per-column dgamma/dbeta in registers across the rows a wave owns; one partial row per block is
 // reduced by xp_splitk_reduce's kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -70,6 +71,79 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
       }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+// bf16 rows with 16-byte accesses: HALF a wave per row (32 lanes x 8 elements per 256-column slab), two adjacent rows per wave
+// in flight, the two statistics of both rows reduced by one 5-step butterfly each (the halves never mix).  The wave-per-row
+// kernel above moves 8 bytes per lane and access; at 18848 x 768 it reached 3.9 TB/s.
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t ldy,
+                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                       int64_t rows, int cols, float eps, LnSide side) {
+  // gamma / beta live in LDS (48 registers otherwise at 768 columns: the row data of two rows in flight is what the register
+  // file should hold)
+  __shared__ __attribute__((aligned(16))) float sgb[2][NJ * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+  for (int c = threadIdx.x * 4; c < NJ * 256; c += 256 * 4) {
+    const bool in = c < cols;
+    store4(&sgb[0][c], in ? load4(gamma + c) : f32x4{0, 0, 0, 0});
+    store4(&sgb[1][c], in ? load4(beta + c) : f32x4{0, 0, 0, 0});
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)cols;
+  for (int64_t row0 = ((int64_t)blockIdx.x * WAVES + wave) * 2; row0 < rows; row0 += (int64_t)gridDim.x * WAVES * 2) {
+    const int64_t row = row0 + half;
+    const bool ok = row < rows;
+    int64_t srow = -1;                               // uniform per half-wave
+    if ((side.xin || side.yout) && ok) {             // 32-bit arithmetic (rows < 2^31, checked by the launcher)
+      const unsigned r = (unsigned)row, q = r / side.S, rem = r - q * side.S;
+      if (rem < side.M) srow = (int64_t)q * side.stride + rem;
+    }
+    const float* xs = (srow >= 0 && side.xin) ? side.xin + srow * cols : nullptr;
+    f32x8 v[NJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = j * 256 + hl * 8;
+      if (ok && c < cols) {
+        v[j] = xs ? load8(xs + c) : load8(x + row * ldx + c);
+        s += (v[j].lo[0] + v[j].lo[1]) + (v[j].lo[2] + v[j].lo[3]) + (v[j].hi[0] + v[j].hi[1]) + (v[j].hi[2] + v[j].hi[3]);
+      } else v[j] = f32x8{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    }
+    const float mu = half_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = j * 256 + hl * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d0 = v[j].lo[e] - mu, d1 = v[j].hi[e] - mu; q += d0 * d0 + d1 * d1; }
+      }
+    }
+    const float rs = rsqrtf(half_sum(q) * inv + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = j * 256 + hl * 8;
+      if (ok && c < cols) {
+        const f32x8 gm = load8(&sgb[0][c]), bt = load8(&sgb[1][c]);
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o.lo[e] = (v[j].lo[e] - mu) * rs * gm.lo[e] + bt.lo[e];
+          o.hi[e] = (v[j].hi[e] - mu) * rs * gm.hi[e] + bt.hi[e];
+        }
+        store8(y + row * ldy + c, o);
+        if (srow >= 0 && side.yout) store8(side.yout + srow * cols + c, o);
+      }
+    }
+    if (hl == 0 && ok) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
@@ -257,7 +331,16 @@ extern "C" int xp_layernorm_fwd_side(const void* x, int64_t ldx, const float* ga
   XP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "xp_layernorm_fwd: ld must be a multiple of 4");
   const int blocks = (int)(cdiv(rows, WAVES) < 4096 ? cdiv(rows, WAVES) : 4096);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == XP_BF16)
+  static const bool half_rows = !getenv("XPRETRAIN_LN_HALFWAVE") || atoi(getenv("XPRETRAIN_LN_HALFWAVE")) != 0;      // (A/B switch)
+  const bool wide16 = dtype == XP_BF16 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
+                      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)x_side | (uintptr_t)y_side) & 15) == 0;
+  if (half_rows && wide16) {
+    const int hb = (int)(cdiv(rows, 2 * WAVES) < 2048 ? cdiv(rows, 2 * WAVES) : 2048);
+    const int nj = (int)cdiv(cols, 256);
+#define XP_LN_FWD_H(NJ) ln_fwd_h_kernel<NJ><<<hb, 256, 0, st>>>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, (int)cols, eps, side)
+    if (nj == 1) XP_LN_FWD_H(1); else if (nj == 2) XP_LN_FWD_H(2); else if (nj == 3) XP_LN_FWD_H(3); else XP_LN_FWD_H(4);
+#undef XP_LN_FWD_H
+  } else if (dtype == XP_BF16)
     ln_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, (int)cols, eps, side);
   else if (dtype == XP_F32)
     ln_fwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, ldx, gamma, beta, (float*)y, ldy, mean, rstd, rows, (int)cols, eps, side);
