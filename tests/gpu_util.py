@@ -61,7 +61,10 @@ TOL = {
     "features_abs_full": 2e-3,     # |vis - ref|, |txt - ref| at every real architecture (cfg1..4, b8): vis <= 6.8e-4, txt <= 1.1e-3
     "cos_abs": 1.5e-3,             # |vis.txt^T - ref|: <= 6.3e-4
     "loss_rel": 2e-2,              # |loss - fp32 reference| / |loss|, north_star's number: <= 9.8e-3
-    "loss_ref_abs": 3e-2,          # absolute, every batch-2 case: <= 2.0e-2 (see above)
+    "loss_ref_abs": 3e-2,          # absolute, every batch-2 case: <= 2.0e-2 on the fixtures; over six input draws per shape the
+                                   # population maximum is 2.5e-2 (tools/loss_seed_study.py, profiles/r04b_loss_seed_study.txt): an
+                                   # absolute 2e-2 would fail one draw in eighteen of a correct build -- north_star's 2e-2 is the
+                                   # RELATIVE gate above (population max 1.4 %)
     "loss_abs": 2e-2,              # |loss - bf16-emulating oracle's loss|: two bf16 computations with the same storage points
     "fp32_abs": 1e-3,              # features and loss in fp32 compute mode (measured 2e-7 / 8.5e-6)
     "hidden_emu": 1.2e-2,          # one layer on the HIP path's own input vs the emulating oracle layer: <= 9.4e-3
