@@ -383,6 +383,13 @@ int xp_encoder_layer_bwd(const XpLayerBwd* args, void* stream);
  * this library relies on (out buffers are small device arrays; see csrc/probe.hip). */
 /* cycle-stamp trace of the 128x128 GEMM main loop (tools/gemm_trace.py); pass NULL to disable.  buffer: >= 1 KiB */
 int xp_debug_set_gemm_trace(void* device_buffer);
+/* In-step timing of ONE GEMM shape: while armed, every xp_gemm call with these (M, N, K, epilogue, operand layouts, split_k) is
+ * bracketed by a pair of HIP events on the stream it is launched on (up to max_launches calls); ..._read disarms, waits for the events and
+ * returns the elapsed times in ms (return value: number of bracketed launches, -1 on error).  bench.py times the dominant kernel of
+ * the step with it INSIDE training steps (isolated launches run at a different power / cache operating point). */
+int xp_debug_gemm_timer_arm(int64_t M, int64_t N, int64_t K, int32_t epilogue, int32_t a_kstrided, int32_t b_kstrided, int32_t split_k,
+                            int32_t max_launches);
+int32_t xp_debug_gemm_timer_read(float* ms, int32_t cap);
 /* cycle stamps of one attention-forward workgroup (start, loads issued, loads landed, loop end); NULL disables */
 int xp_debug_set_attn_trace(void* device_buffer);
 /* resident workgroups per CU of the default bf16 GEMM kernel at `lds_bytes` of dynamic LDS (occupancy API) */

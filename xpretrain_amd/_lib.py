@@ -146,6 +146,8 @@ SIGNATURES = {
     "xp_encoder_layer_bwd_workspace_bytes": (sz, [C.POINTER(XpLayerDims)]),
     "xp_encoder_layer_bwd": (i32, [C.POINTER(XpLayerBwd), vp]),
     "xp_debug_set_gemm_trace": (i32, [vp]),
+    "xp_debug_gemm_timer_arm": (i32, [i64, i64, i64, i32, i32, i32, i32, i32]),
+    "xp_debug_gemm_timer_read": (i32, [C.POINTER(C.c_float), i32]),
     "xp_debug_set_attn_trace": (i32, [vp]),
     "xp_debug_gemm_occupancy": (i32, [i32]),
     "xp_probe_mfma_bf16": (i32, [vp, vp, vp, vp]),

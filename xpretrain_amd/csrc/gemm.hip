@@ -16,6 +16,8 @@
 #include "common.h"
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -533,6 +535,64 @@ extern "C" int xp_debug_gemm_occupancy(int lds_bytes) {
 static unsigned long long* g_gemm_trace = nullptr;
 extern "C" int xp_debug_set_gemm_trace(void* device_buffer) { g_gemm_trace = (unsigned long long*)device_buffer; return XP_OK; }
 
+// ---- in-step timing of ONE GEMM shape (bench.py's roofline: the dominant kernel timed where it runs, inside training steps) ----
+// While armed, every xp_gemm call whose (M, N, K, epilogue, operand layout, split) match is bracketed by a pair of HIP events on
+// the stream it is launched on; xp_debug_gemm_timer_read synchronises them and returns the elapsed times.  Host-side only (two
+// hipEventRecord per matching launch); not armed, it costs one pointer test per xp_gemm call.
+namespace {
+struct GemmTimer {
+  std::mutex mu;
+  bool armed = false;
+  int64_t M = 0, N = 0, K = 0; int epi = 0, aks = 0, bks = 0, split = 1;
+  std::vector<hipEvent_t> ev;      // pairs: start, stop
+  size_t used = 0;
+} g_timer;
+static volatile bool g_timer_on = false;
+}  // namespace
+
+extern "C" int xp_debug_gemm_timer_arm(int64_t M, int64_t N, int64_t K, int32_t epilogue, int32_t a_kstrided, int32_t b_kstrided,
+                                       int32_t split_k, int32_t max_launches) {
+  XP_REQUIRE(max_launches > 0 && max_launches <= 4096, "xp_debug_gemm_timer_arm: max_launches must be 1..4096");
+  std::lock_guard<std::mutex> lock(g_timer.mu);
+  while (g_timer.ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { xp_set_error("xp_debug_gemm_timer_arm: hipEventCreate failed"); return XP_ERR_LAUNCH; }
+    g_timer.ev.push_back(e);
+  }
+  g_timer.M = M; g_timer.N = N; g_timer.K = K; g_timer.epi = epilogue; g_timer.aks = a_kstrided; g_timer.bks = b_kstrided;
+  g_timer.split = split_k > 1 ? split_k : 1;
+  g_timer.used = 0; g_timer.armed = true; g_timer_on = true;
+  return XP_OK;
+}
+
+// disarms; writes up to `cap` elapsed times (ms) of the bracketed launches, returns how many were bracketed (-1 on error)
+extern "C" int32_t xp_debug_gemm_timer_read(float* ms, int32_t cap) {
+  std::lock_guard<std::mutex> lock(g_timer.mu);
+  g_timer_on = false; g_timer.armed = false;
+  const int n = (int)(g_timer.used / 2);
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (hipEventSynchronize(g_timer.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms[i], g_timer.ev[2 * i], g_timer.ev[2 * i + 1]) != hipSuccess) {
+      xp_set_error("xp_debug_gemm_timer_read: event query failed");
+      return -1;
+    }
+  }
+  g_timer.used = 0;
+  return n;
+}
+
+// returns the index of the event pair to record around this launch, or -1
+static int gemm_timer_slot(const XpGemmDesc* d, int split) {
+  if (!g_timer_on) return -1;
+  std::lock_guard<std::mutex> lock(g_timer.mu);
+  if (!g_timer.armed || d->M != g_timer.M || d->N != g_timer.N || d->K != g_timer.K || d->epilogue != g_timer.epi ||
+      (d->a_kstrided != 0) != (g_timer.aks != 0) || (d->b_kstrided != 0) != (g_timer.bks != 0) || split != g_timer.split ||
+      g_timer.used + 2 > g_timer.ev.size())
+    return -1;
+  const int slot = (int)g_timer.used;
+  g_timer.used += 2;
+  return slot;
+}
+
 extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   XP_REQUIRE(d && d->A && d->B && d->C, "xp_gemm: null operand");
   XP_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "xp_gemm: empty problem M=%lld N=%lld K=%lld",
@@ -594,6 +654,9 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
              split, (long long)d->K, zsplits);
   dim3 grid(kp.tiles_m * kp.tiles_n, 1, split);
   hipStream_t st = (hipStream_t)stream;
+  const int tslot = gemm_timer_slot(d, split);                       // (debug: in-step timing of one shape)
+  if (tslot >= 0) (void)hipEventRecord(g_timer.ev[tslot], st);
+  struct Stop { int slot; hipStream_t st; ~Stop() { if (slot >= 0) (void)hipEventRecord(g_timer.ev[slot + 1], st); } } stop{tslot, st};
   if (xp_gemm256_try(d, kp, st)) {     // large dense problems: 256x256 ping-pong family
     XP_CHECK_LAUNCH("xp_gemm(256)");
     return XP_OK;
