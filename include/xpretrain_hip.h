@@ -86,6 +86,13 @@ typedef struct XpGemmDesc {
    * out_side (same indexing) next to the rounded C row.  The pooled feature is token 0 of the last layer: keeping the residual
    * stream of these few rows in fp32 halves the feature error of the bf16 path (tools/residual_precision_experiment.py). */
   const float* resid_side; float* out_side; int64_t side_S;
+  /* optional: A is not a matrix in memory but the patch matrix of a frame tensor, gathered by the operand loader -- the conv-as-GEMM
+   * of CLIPVisionViPEmbeddings.patch_embedding (CLIP_ViP.py:157-159,178) without the im2col round trip.  a_frames: [BT,3,H,W], fp32 or
+   * (a_frames_u8 = 1) decoded uint8 with the collate arithmetic (x / 255 - fr_mean[c]) / fr_std[c] (datasets/dataloader.py:209-233)
+   * fused in; M = BT * (H/P) * (W/P) patches in (bt, gy, gx) order, K = 3*P*P in (c, dy, dx) order; A / lda are ignored.  The gathered
+   * values are rounded to bf16 exactly as xp_im2col / xp_im2col_u8 round them (same result as the materialised matrix, bit for
+   * bit).  bf16 compute, P % 8 == 0, no split-K. */
+  const void* a_frames; int32_t a_frames_u8; int32_t fr_H, fr_W, fr_P; float fr_mean[3], fr_std[3];
 } XpGemmDesc;
 
 int xp_gemm(const XpGemmDesc* desc, void* stream);

@@ -156,3 +156,52 @@ def test_vsc_fc_loss_large_n_fp64():
     for name, g, r in zip(("dV", "dT", "dI", "dC"), out[1:5], rg[:4]):
         assert report(f"vsc_fc200 {name}", g, r, 1e-4) <= 1e-4
     assert abs(out[5].item() - rg[4].item()) <= 1e-4 * max(1.0, abs(rg[4].item()))
+
+
+@pytest.mark.parametrize("u8", [False, True])
+@pytest.mark.parametrize("P,R,BT", [(16, 224, 5), (32, 224, 3), (16, 64, 7), (8, 40, 2)])
+def test_patch_gather_in_the_gemm_loader(u8, P, R, BT):
+    """XpGemmDesc::a_frames: the conv-as-GEMM of the patch embedding (CLIP_ViP.py:157-159,178) with the patch matrix gathered by
+    the operand loader straight from [BT,3,H,W] (fp32, or decoded uint8 with the collate arithmetic fused in) -- bit-identical to
+    the materialised im2col matrix through the same GEMM, plain and with the embedding epilogue (+temporal +position, token slots),
+    ragged last tile included."""
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd import _lib as L
+    torch.manual_seed(P + R + BT)
+    bf = torch.bfloat16
+    g = R // P
+    Lp, K, D = g * g, 3 * P * P, 256
+    if u8:
+        frames = torch.randint(0, 256, (BT, 3, R, R), dtype=torch.uint8, device="cuda")
+        patches = H.im2col_u8(frames, P, bf)
+        kw = dict(frames=frames, frame_patch=P, frame_norm=(H.CLIP_MEAN, H.CLIP_STD))
+    else:
+        frames = torch.randn(BT, 3, R, R, device="cuda")
+        patches = H.im2col(frames, P, bf)
+        kw = dict(frames=frames, frame_patch=P)
+    W = (torch.randn(D, K, device="cuda") * 0.05).to(bf)
+    M = BT * Lp
+    want = H.gemm(patches, W, M, D, K)
+    got = H.gemm(None, W, M, D, K, **kw)
+    assert torch.equal(got, want)
+    ref = patches.double() @ W.double().t()
+    assert report(f"patch gather P{P} R{R} u8={u8}", got, ref, 6e-3) <= 6e-3
+    # the embedding epilogue: + temporal[t] + position[1 + l], written to token slot Mp + t*L + l of sample b
+    T, Mp = 1, 4
+    Bv = BT // T
+    S = Mp + T * Lp
+    tt, pos = torch.randn(T, D, device="cuda"), torch.randn(Lp, D, device="cuda")
+    x0 = torch.zeros(Bv * S, D, dtype=bf, device="cuda"); x1 = torch.zeros_like(x0)
+    H.gemm(patches, W, M, D, K, out=x0, epilogue=L.EPI_PATCH, tab1=tt, tab2=pos, tab_L=Lp, c_remap=(T * Lp, S, Mp))
+    H.gemm(None, W, M, D, K, out=x1, epilogue=L.EPI_PATCH, tab1=tt, tab2=pos, tab_L=Lp, c_remap=(T * Lp, S, Mp), **kw)
+    assert torch.equal(x0, x1)
+
+
+def test_patch_gather_rejects_what_it_cannot_do():
+    from xpretrain_amd import hip_ops as H
+    frames = torch.randn(2, 3, 32, 32, device="cuda")
+    W = torch.zeros(64, 3 * 16 * 16, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="a_frames"):
+        H.gemm(None, W, 2 * 4, 64, 3 * 16 * 16 - 8, frames=frames, frame_patch=16)          # K != 3*P*P
+    with pytest.raises(TypeError):
+        H.gemm(None, W, 8, 64, 768, frames=frames.to(torch.uint8), frame_patch=16)          # uint8 without the normalisation constants

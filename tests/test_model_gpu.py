@@ -366,3 +366,36 @@ def test_gradient_checkpointing_recomputes_bit_identically():
     bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
     assert not bad, bad[:5]
     print(f"peak memory without / with checkpointing: {m0 / 2**20:.0f} / {m1 / 2**20:.0f} MiB (tiny model: cached workspaces dominate)")
+
+
+def test_inference_forward_gathers_patches_in_the_gemm(monkeypatch):
+    """torch.no_grad() / frozen patch embedding: VisionEmbedFn lets the GEMM loader gather the patches (no im2col pass, no patch
+    matrix); the features are bit-identical to the materialised path, for fp32 and uint8 frames; a training pass still materialises
+    (dW reads the matrix)."""
+    import xpretrain_amd.functional as XF
+    from xpretrain_amd import hip_ops as H
+    from xpretrain_amd.modeling import VidCLIP
+    torch.manual_seed(3)
+    cfgd = O.hf_config_dict(128, 2, 2, 256, 16, 32, 128, 2, 2, 256, 120, 16, 64)
+    model = VidCLIP(_Args(cfgd, 3)).cuda().eval()
+    video, ids, mask = (t.cuda() for t in O.synthetic_inputs(2, 3, 32, 12, vocab=120))
+    calls = []
+    orig = H.im2col
+    monkeypatch.setattr(H, "im2col", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad():
+        a = model.forward_video(video)
+        assert not calls                                      # gathered by the loader
+        monkeypatch.setattr(XF, "PATCH_GATHER", False)
+        b = model.forward_video(video)
+        assert calls
+        monkeypatch.setattr(XF, "PATCH_GATHER", True)
+        u8 = (video.clamp(-1, 1) * 127 + 128).to(torch.uint8)
+        c = model.forward_video(u8)
+        monkeypatch.setattr(XF, "PATCH_GATHER", False)
+        d = model.forward_video(u8)
+    assert torch.equal(a, b) and torch.equal(c, d)
+    monkeypatch.setattr(XF, "PATCH_GATHER", True)
+    calls.clear()
+    model.train()
+    model(video, ids, mask)["vis_features"].sum().backward()  # training: the matrix is needed for dW
+    assert calls and model.clipmodel.vision_model.embeddings.patch_embedding.weight.grad is not None

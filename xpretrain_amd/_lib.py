@@ -41,6 +41,8 @@ class XpGemmDesc(C.Structure):
         ("colsum_partials", vp),
         ("reserved0", i32), ("side_M", i32),
         ("resid_side", vp), ("out_side", vp), ("side_S", i64),
+        ("a_frames", vp), ("a_frames_u8", i32), ("fr_H", i32), ("fr_W", i32), ("fr_P", i32),
+        ("fr_mean", f32 * 3), ("fr_std", f32 * 3),
     ]
 
 

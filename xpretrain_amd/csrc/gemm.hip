@@ -43,6 +43,58 @@ __device__ __forceinline__ void gload_kc(u32x4 (&r)[4], const T* base, int64_t l
       r[j] = u32x4{0, 0, 0, 0};
   }
 }
+// The patch matrix of a frame tensor as the k-contiguous A operand, gathered on the fly (the conv-as-GEMM of
+// CLIPVisionViPEmbeddings.patch_embedding, CLIP_ViP.py:157-159,178): row m = patch (bt, gy, gx), k = (c, dy, dx); a thread's 8
+// consecutive k are 8 consecutive pixels of one 16-pixel strip -- 32 contiguous bytes of fp32 frames (8 of uint8 frames) -- read
+// straight from [BT,3,H,W], converted (uint8: the collate arithmetic (x / 255 - mean[c]) / std[c], same operation order as
+// xp_im2col_u8) and rounded to bf16 exactly like xp_im2col / xp_im2col_u8 do: the staged tile is bit-identical to a tile of the
+// materialised matrix.  The four rows of a thread are fixed over the k loop: their frame offsets are computed once (im2col_rows).
+struct Im2colRows { int64_t base[4]; bool ok[4]; };
+__device__ __forceinline__ Im2colRows im2col_rows(const KParams& p, int64_t row0, int tid) {
+  Im2colRows r;
+  const int rr = tid >> 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t m = row0 + rr + 32 * j;
+    r.ok[j] = m < p.M;
+    const int64_t mm = r.ok[j] ? m : 0;
+    const int64_t bt = mm / p.im_L;
+    const int l = (int)(mm - bt * p.im_L), gy = l / p.im_gw, gx = l - gy * p.im_gw;
+    r.base[j] = (bt * 3 * p.im_H + (int64_t)gy * p.im_P) * p.im_W + (int64_t)gx * p.im_P;
+  }
+  return r;
+}
+template <bool U8>
+__device__ __forceinline__ void gload_im2col(u32x4 (&r)[4], const KParams& p, const Im2colRows& rows, int64_t k0, int64_t kend, int tid) {
+  const int c8 = tid & 7;
+  const int64_t k = k0 + c8 * 8;
+  const int pp = p.im_P * p.im_P;
+  const int ch = (int)(k / pp), rem = (int)(k - (int64_t)ch * pp), dy = rem / p.im_P, dx = rem - dy * p.im_P;
+  const int64_t koff = ((int64_t)ch * p.im_H + dy) * p.im_W + dx;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (rows.ok[j] && k < kend) {
+      f32x4 a, b;
+      if constexpr (!U8) {
+        const float* src = reinterpret_cast<const float*>(p.im_src) + rows.base[j] + koff;
+        a = load4(src); b = load4(src + 4);
+      } else {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.im_src) + rows.base[j] + koff);
+        const float mean = p.im_mean[ch], sd = p.im_std[ch];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = ((float)((raw[0] >> (8 * e)) & 0xFF) / 255.0f - mean) / sd;
+          b[e] = ((float)((raw[1] >> (8 * e)) & 0xFF) / 255.0f - mean) / sd;
+        }
+      }
+      const bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+      r[j] = __builtin_bit_cast(u32x4, o);
+    } else {
+      r[j] = u32x4{0, 0, 0, 0};
+    }
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void lstore_kc(char* tile, const u32x4 (&r)[4], int tid) {
   const int c = tid & 7, rr = tid >> 3;
@@ -179,8 +231,10 @@ __device__ __forceinline__ typename Frag<T>::type lfrag(const char* tile, int ot
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
-template <typename T, bool AKS, bool BKS, bool GLDS>
+// AIM: 0 = A is a matrix; 1 / 2 = A is gathered from fp32 / uint8 frames (register-staged bf16 NT kernel only)
+template <typename T, bool AKS, bool BKS, bool GLDS, int AIM = 0>
 __global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
+  static_assert(AIM == 0 || (!AKS && !GLDS && sizeof(T) == 2), "on-the-fly patch gather: bf16, k-contiguous A, register staging");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto sA = [&](int s) -> char* { return smem + (2 * s) * TILE_BYTES; };
   auto sB = [&](int s) -> char* { return smem + (2 * s + 1) * TILE_BYTES; };
@@ -216,8 +270,11 @@ __global__ __launch_bounds__(GLDS ? 2 * NT : NT) void gemm_kernel(KParams p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[4], rb[4];
+  Im2colRows imr;
+  if constexpr (AIM != 0) imr = im2col_rows(p, m0, tid);
   auto gload = [&](int64_t k0) {
-    if constexpr (AKS) gload_ks<T>(ra, A, p.lda, m0, p.M, k0, kend, p.amap, tid);
+    if constexpr (AIM != 0) gload_im2col<AIM == 2>(ra, p, imr, k0, kend, tid);
+    else if constexpr (AKS) gload_ks<T>(ra, A, p.lda, m0, p.M, k0, kend, p.amap, tid);
     else               gload_kc<T>(ra, A, p.lda, m0, p.M, k0, kend, p.amap, tid);
     if constexpr (BKS) gload_ks<T>(rb, B, p.ldb, n0, p.N, k0, kend, ident, tid);
     else               gload_kc<T>(rb, B, p.ldb, n0, p.N, k0, kend, ident, tid);
@@ -389,6 +446,14 @@ bool glds_ok(const XpGemmDesc* d, int esz) {
 
 template <typename T>
 int launch(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (d->a_frames) {                  // A gathered from the frame tensor by the loader
+      const size_t lds = 4 * TILE_BYTES;
+      if (d->a_frames_u8) gemm_kernel<T, false, false, false, 2><<<grid, NT, lds, st>>>(kp);
+      else                gemm_kernel<T, false, false, false, 1><<<grid, NT, lds, st>>>(kp);
+      return 0;
+    }
+  }
   if (glds_ok(d, sizeof(T))) launch2<T, true>(d, kp, grid, st);
   else                       launch2<T, false>(d, kp, grid, st);
   return 0;
@@ -594,7 +659,7 @@ static int gemm_timer_slot(const XpGemmDesc* d, int split) {
 }
 
 extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
-  XP_REQUIRE(d && d->A && d->B && d->C, "xp_gemm: null operand");
+  XP_REQUIRE(d && (d->A || d->a_frames) && d->B && d->C, "xp_gemm: null operand");
   XP_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "xp_gemm: empty problem M=%lld N=%lld K=%lld",
              (long long)d->M, (long long)d->N, (long long)d->K);
   XP_REQUIRE(d->in_dtype == XP_BF16 || d->in_dtype == XP_F32, "xp_gemm: bad in_dtype %d", d->in_dtype);
@@ -607,6 +672,16 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
              "xp_gemm: contiguous extents / leading dims must be multiples of %d elements", epc);
   XP_REQUIRE(d->N % 4 == 0 && d->ldc % 4 == 0, "xp_gemm: N and ldc must be multiples of 4");
   XP_REQUIRE(((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) % 16 == 0, "xp_gemm: operands must be 16-byte aligned");
+  if (d->a_frames) {
+    const int64_t P = d->fr_P, gh = P > 0 ? d->fr_H / P : 0, gw = P > 0 ? d->fr_W / P : 0;
+    XP_REQUIRE(d->in_dtype == XP_BF16 && !d->a_kstrided && !d->b_kstrided && d->a_grp == 0 && (d->split_k <= 1),
+               "xp_gemm: a_frames needs bf16 compute, k-contiguous operands, no row remap of A, no split-K");
+    XP_REQUIRE(P > 0 && P % 8 == 0 && d->fr_H % P == 0 && d->fr_W % P == 0 && d->K == 3 * P * P && gh * gw > 0 && d->M % (gh * gw) == 0,
+               "xp_gemm: a_frames needs P %% 8 == 0, H and W multiples of P, K == 3*P*P and M a multiple of the patches per frame");
+    XP_REQUIRE(((uintptr_t)d->a_frames & (d->a_frames_u8 ? 7 : 15)) == 0 && (d->a_frames_u8 ? d->fr_W % 8 == 0 : d->fr_W % 4 == 0),
+               "xp_gemm: a_frames must be 16-byte (fp32) / 8-byte (uint8) aligned with a row pitch that keeps 8-pixel strips aligned");
+    if (d->a_frames_u8) for (int c = 0; c < 3; ++c) XP_REQUIRE(d->fr_std[c] > 0.f, "xp_gemm: fr_std[%d] must be positive", c);
+  }
   const int ep = d->epilogue;
   XP_REQUIRE(ep >= XP_EPI_NONE && ep <= XP_EPI_SCALE, "xp_gemm: bad epilogue %d", ep);
   if (ep == XP_EPI_BIAS || ep == XP_EPI_BIAS_QSCALE || ep == XP_EPI_BIAS_GELU || ep == XP_EPI_BIAS_RESID)
@@ -630,6 +705,9 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
   kp.resid = d->resid; kp.ldr = d->ldr; kp.aux = d->aux; kp.ldaux = d->ldaux;
   kp.tab1 = d->tab1; kp.tab2 = d->tab2; kp.tab_L = d->tab_L;
   kp.dbg = g_gemm_trace; kp.flat_split = 0;
+  kp.im_src = d->a_frames; kp.im_u8 = d->a_frames_u8; kp.im_H = d->fr_H; kp.im_W = d->fr_W; kp.im_P = d->fr_P;
+  kp.im_gw = d->fr_P > 0 ? d->fr_W / d->fr_P : 1; kp.im_L = d->fr_P > 0 ? (d->fr_H / d->fr_P) * kp.im_gw : 1;
+  for (int c = 0; c < 3; ++c) { kp.im_mean[c] = d->fr_mean[c]; kp.im_std[c] = d->fr_std[c]; }
   kp.wide = (d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0)) ? 1 : 0;
   kp.fast_epi = (kp.wide && xp_gemm_fast_epi_ok(d)) ? 1 : 0;
   kp.colsum = d->colsum_partials;

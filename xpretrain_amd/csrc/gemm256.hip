@@ -349,7 +349,7 @@ static bool epi_supported(const XpGemmDesc* d) {
 
 // preconditions of the family that do not depend on split_k
 bool xp_gemm256_legal(const XpGemmDesc* d) {
-  if (d->in_dtype != XP_BF16 || d->a_grp != 0) return false;
+  if (d->in_dtype != XP_BF16 || d->a_grp != 0 || d->a_frames) return false;      // (a_frames: the register-staged 128x128 loader gathers)
   const int64_t a_rows = d->a_kstrided ? d->K : d->M, b_rows = d->b_kstrided ? d->K : d->N;
   if (!d->a_kstrided && (d->K % KE != 0 || d->lda != d->K)) return false;
   if (!d->b_kstrided && (d->K % KE != 0 || d->ldb != d->K)) return false;

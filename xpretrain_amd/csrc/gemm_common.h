@@ -31,6 +31,8 @@ struct KParams {
   const float* rside; float* oside; unsigned side_S, side_M;   // BIAS_RESID: fp32 side rows of the residual stream (XpGemmDesc)
   unsigned long long* dbg;   // optional cycle-stamp trace buffer (xp_debug_set_gemm_trace), else null
   int flat_split;            // gemm256s split-K launches: > 0 = the grid is 1-D over (k-chunk, tile), chunk-major per XCD (see kernel)
+  // A gathered from a frame tensor by the loader (XpGemmDesc::a_frames): frames [BT,3,H,W] fp32 (im_u8 == 0) or uint8 (im_u8 == 1)
+  const void* im_src; int im_u8, im_H, im_W, im_P, im_gw, im_L; float im_mean[3], im_std[3];
 };
 
 

@@ -521,6 +521,10 @@ def with_side_rows(x: torch.Tensor, side: Optional[torch.Tensor], B: int, S: int
     return h
 
 
+# XPRETRAIN_PATCH_GATHER=0: always materialise the patch matrix (A/B switch for the on-the-fly gather in the GEMM loader)
+PATCH_GATHER = os.environ.get("XPRETRAIN_PATCH_GATHER", "1") != "0"
+
+
 # ------------------------------------------------------------------------------------------ embeddings
 class VisionEmbedFn(torch.autograd.Function):
     """CLIPVisionViPEmbeddings.forward (modeling/CLIP_ViP.py:168-197): conv patch embed as im2col + MFMA GEMM
@@ -539,16 +543,29 @@ class VisionEmbedFn(torch.autograd.Function):
         if pos_w.shape[0] != 1 + Lp:
             raise ValueError(f"position_embedding has {pos_w.shape[0]} rows but the frame has {Lp} patches (+1)")
         K = 3 * P * P
-        if video.dtype == torch.uint8:     # decoded frames: /255, CLIP mean/std and the cast happen inside the gather
-            patches = H.im2col_u8(video.reshape(Bv * T, Cc, Hh, Ww).contiguous(), P, dtype)
-        else:
-            patches = H.im2col(video.reshape(Bv * T, Cc, Hh, Ww).contiguous().float(), P, dtype)
+        frames = video.reshape(Bv * T, Cc, Hh, Ww).contiguous()
+        if frames.dtype != torch.uint8:
+            frames = frames.float()
         Wp = WEIGHTS.get(patch_w, dtype).view(D, K)
         x = torch.empty((Bv * S, D), dtype=dtype, device=video.device)
         pos = pos_w.detach().contiguous()
         tt = time_table.detach().contiguous().float()
-        H.gemm(patches, Wp, Bv * T * Lp, D, K, out=x, epilogue=L.EPI_PATCH, tab1=tt, tab2=pos[1:], tab_L=Lp,
-               c_remap=(T * Lp, S, M))
+        # The patch matrix is only materialised when the backward needs it (dW of the patch embedding reads it k-strided).  A pass
+        # that does not (inference, a frozen patch embedding) lets the GEMM's operand loader gather the 8-pixel strips straight from
+        # [BT,3,H,W] (XpGemmDesc::a_frames): same bf16 operand values, no im2col round trip.
+        need_patches = torch.is_grad_enabled() and patch_w.requires_grad
+        on_the_fly = (not need_patches and PATCH_GATHER and dtype == torch.bfloat16 and P % 8 == 0 and Ww % 8 == 0)
+        patches = None
+        if on_the_fly:
+            H.gemm(None, Wp, Bv * T * Lp, D, K, out=x, epilogue=L.EPI_PATCH, tab1=tt, tab2=pos[1:], tab_L=Lp, c_remap=(T * Lp, S, M),
+                   frames=frames, frame_patch=P, frame_norm=(H.CLIP_MEAN, H.CLIP_STD) if frames.dtype == torch.uint8 else None)
+        else:
+            if frames.dtype == torch.uint8:     # decoded frames: /255, CLIP mean/std and the cast happen inside the gather
+                patches = H.im2col_u8(frames, P, dtype)
+            else:
+                patches = H.im2col(frames, P, dtype)
+            H.gemm(patches, Wp, Bv * T * Lp, D, K, out=x, epilogue=L.EPI_PATCH, tab1=tt, tab2=pos[1:], tab_L=Lp,
+                   c_remap=(T * Lp, S, M))
         H.vip_proxy_rows(class_emb.detach(), added_cls.detach().contiguous(), pos, x, Bv, S, M, D)
         ctx.save_for_backward(patches)
         ctx.meta = (Bv, T, Lp, M, S, D, K, tuple(patch_w.shape), added_cls.shape[0])
@@ -560,7 +577,7 @@ class VisionEmbedFn(torch.autograd.Function):
         Bv, T, Lp, M, S, D, K, wshape, nadd = ctx.meta
         dx = dx.contiguous()
         d_class, d_added, d_pos, d_time = H.vip_embed_bwd(dx, Bv, M, T, Lp, D)
-        dwp = _wgrad(dx, patches, Bv * T * Lp, D, K, a_remap=(T * Lp, S, M)).view(wshape)
+        dwp = None if patches is None else _wgrad(dx, patches, Bv * T * Lp, D, K, a_remap=(T * Lp, S, M)).view(wshape)
         return None, dwp, d_class, d_added[:nadd], d_pos, d_time, None
 
 

@@ -60,13 +60,23 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
          a_kstrided=False, b_kstrided=False, out_dtype=None, epilogue=L.EPI_NONE, bias=None, scale=1.0,
          scale_cols=0, resid=None, ldr=None, aux=None, ldaux=None, tab1=None, tab2=None, tab_L=0,
          a_remap=(0, 0, 0), c_remap=(0, 0, 0), split_k=1, out_rows=None, colsum_defer=None, colsum_name="gemm_colsum",
-         resid_side=None, out_side=None, side=None):
+         resid_side=None, out_side=None, side=None, frames=None, frame_patch=0, frame_norm=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/xpretrain_hip.h::XpGemmDesc.
+
+    ``frames`` ([BT,3,H,W] fp32 or uint8, contiguous) with ``frame_patch`` = P: A is the patch matrix of the frames, gathered by the
+    operand loader (no im2col pass; pass ``A=None``); uint8 frames need ``frame_norm = (mean3, std3)``.
 
     ``colsum_defer`` (a DeferredReduce): also return the column sums of C (a bias gradient), as ``(C, colsum)``; the
     sums come out of the GEMM epilogue where the library supports it, otherwise from a separate pass over C; either
     way they are final only after ``colsum_defer.flush()``."""
-    _chk(A, "A"); _chk(B, "B", A.dtype)
+    if frames is not None:
+        _chk(frames, "frames"); _chk(B, "B", torch.bfloat16)
+        if A is not None or frames.dim() != 4 or frames.shape[1] != 3 or not frames.is_contiguous() or \
+                frames.dtype not in (torch.float32, torch.uint8) or (frames.dtype == torch.uint8 and frame_norm is None):
+            raise TypeError("gemm: frames must be a contiguous [BT,3,H,W] fp32 / uint8 (with frame_norm) tensor and A must be None")
+        A = B                                          # (dtype / device of the compute path; the descriptor's A stays NULL)
+    else:
+        _chk(A, "A"); _chk(B, "B", A.dtype)
     out_dtype = out_dtype or A.dtype
     if split_k > 1:
         out = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device) if out is None else out
@@ -74,7 +84,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     elif out is None:
         out = torch.empty((out_rows or M, N), dtype=out_dtype, device=A.device)
     d = L.XpGemmDesc()
-    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    d.A, d.B, d.C = (0 if frames is not None else A.data_ptr()), B.data_ptr(), out.data_ptr()
+    if frames is not None:
+        d.a_frames, d.a_frames_u8 = frames.data_ptr(), int(frames.dtype == torch.uint8)
+        d.fr_H, d.fr_W, d.fr_P = frames.shape[2], frames.shape[3], int(frame_patch)
+        if frame_norm is not None:
+            for c in range(3):
+                d.fr_mean[c], d.fr_std[c] = float(frame_norm[0][c]), float(frame_norm[1][c])
     d.M, d.N, d.K = M, N, K
     d.lda = lda if lda is not None else (M if a_kstrided else K)
     d.ldb = ldb if ldb is not None else (N if b_kstrided else K)
