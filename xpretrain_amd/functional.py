@@ -533,7 +533,9 @@ class VisionEmbedFn(torch.autograd.Function):
     table (already interpolated by the caller when T != temporal_size, :171-174)."""
 
     @staticmethod
-    def forward(ctx, video, patch_w, class_emb, added_cls, pos_w, time_table, dtype):
+    def forward(ctx, video, patch_w, class_emb, added_cls, pos_w, time_table, dtype, want_wgrad=True):
+        """``want_wgrad``: the caller's ``torch.is_grad_enabled() and patch_w.requires_grad`` (grad mode is off inside
+        Function.forward, and ``ctx.needs_input_grad`` ignores ``torch.no_grad()``): False lets the loader gather the patches."""
         Bv, T, Cc, Hh, Ww = video.shape
         D, _, P, _ = patch_w.shape
         gh, gw = Hh // P, Ww // P
@@ -553,7 +555,7 @@ class VisionEmbedFn(torch.autograd.Function):
         # The patch matrix is only materialised when the backward needs it (dW of the patch embedding reads it k-strided).  A pass
         # that does not (inference, a frozen patch embedding) lets the GEMM's operand loader gather the 8-pixel strips straight from
         # [BT,3,H,W] (XpGemmDesc::a_frames): same bf16 operand values, no im2col round trip.
-        need_patches = torch.is_grad_enabled() and patch_w.requires_grad
+        need_patches = bool(want_wgrad) and ctx.needs_input_grad[1]
         on_the_fly = (not need_patches and PATCH_GATHER and dtype == torch.bfloat16 and P % 8 == 0 and Ww % 8 == 0)
         patches = None
         if on_the_fly:
@@ -578,7 +580,7 @@ class VisionEmbedFn(torch.autograd.Function):
         dx = dx.contiguous()
         d_class, d_added, d_pos, d_time = H.vip_embed_bwd(dx, Bv, M, T, Lp, D)
         dwp = None if patches is None else _wgrad(dx, patches, Bv * T * Lp, D, K, a_remap=(T * Lp, S, M)).view(wshape)
-        return None, dwp, d_class, d_added[:nadd], d_pos, d_time, None
+        return None, dwp, d_class, d_added[:nadd], d_pos, d_time, None, None
 
 
 class TextEmbedFn(torch.autograd.Function):

@@ -146,8 +146,9 @@ class CLIPVisionViPEmbeddings(nn.Module):
             time_table = te[0]
         else:
             time_table = torch.zeros(T, self.embed_dim, device=pixel_values.device)
-        x = XF.VisionEmbedFn.apply(pixel_values, self.patch_embedding.weight, self.class_embedding, self.added_cls,
-                                   self.position_embedding.weight, time_table, dtype)
+        pw = self.patch_embedding.weight
+        x = XF.VisionEmbedFn.apply(pixel_values, pw, self.class_embedding, self.added_cls, self.position_embedding.weight, time_table, dtype,
+                                   torch.is_grad_enabled() and pw.requires_grad)
         M = 1 + self.add_cls_num
         L = (H // self.patch_size) * (W // self.patch_size)
         return x, (M, T, L)          # x: [B*(M+T*L), D]
