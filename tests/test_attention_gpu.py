@@ -45,7 +45,10 @@ def _run(B, H, size, S, pad_mask, seed, scale=1.0, spike=False, q_scale=1.0, dty
 
 @pytest.mark.parametrize("size,B,H", [((4, 2, 49), 2, 2), ((4, 12, 196), 1, 2), ((1, 3, 5), 2, 1), ((4, 3, 70), 1, 3),
                                       ((2, 5, 16), 2, 3), ((4, 1, 196), 1, 1), ((4, 2, 784), 1, 1), ((4, 32, 196), 1, 1),
-                                      ((20, 3, 49), 1, 2), ((17, 2, 180), 1, 1)])      # > 16 proxy tokens: outside the persistent kernel's mask
+                                      ((20, 3, 49), 1, 2), ((17, 2, 180), 1, 1),       # > 16 proxy tokens: outside the persistent kernel's mask
+                                      ((4, 3, 300), 2, 2), ((2, 2, 500), 1, 3), ((4, 5, 208), 1, 2), ((1, 2, 1023), 1, 1),
+                                      ((4, 9, 784), 2, 3)])      # multi-group persistent kernel: 2..5 key groups, 2..4 query blocks, many problems
+
 def test_proxy_attention(size, B, H):
     M, N, L = size
     _run(B, H, size, M + N * L, None, seed=M + N + L)

@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -320,7 +321,7 @@ constexpr int F3_LDS = 2 * F3_BUF;
 
 // K and V rows [0, R) of one problem -> linear swizzled LDS images by LDS-DMA: one wave instruction = 8 rows x 128 B; the
 // XOR swizzle of tile128_off is applied to the per-lane SOURCE chunk; rows >= R read as zero (out-of-range offset)
-__device__ __forceinline__ void fwd3_stage_kv(char* gK, char* gV, const AP& p, const Prob& pr, int lane, int wave) {
+__device__ __forceinline__ void fwd3_stage_kv(char* gK, char* gV, const AP& p, const Prob& pr, int lane, int wave, int row0 = 0) {
   typedef __attribute__((address_space(3))) char lds_c;
   const bf16_t* kbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + (int64_t)p.H * DH + pr.h * DH;
   const unsigned ld_bytes = (unsigned)(p.ldqkv * 2), voff_v = (unsigned)(p.H * DH * 2);
@@ -333,18 +334,18 @@ __device__ __forceinline__ void fwd3_stage_kv(char* gK, char* gV, const AP& p, c
     if (pass < NPASS) {
       const int row = pass * 8 + (lane >> 3);
       const int c = (lane & 7) ^ swz128(row);
-      const unsigned off = row < p.R ? (unsigned)tok_of(p, pr.n, row) * ld_bytes + c * 16 : 0xFFFFFF00u;
+      const unsigned off = row0 + row < p.R ? (unsigned)tok_of(p, pr.n, row0 + row) * ld_bytes + c * 16 : 0xFFFFFF00u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(gK + pass * 1024), 16, off, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(gV + pass * 1024), 16, off, voff_v, 0, 0);
     }
   }
 }
 // the wave's Q rows as B-operand fragments
-__device__ __forceinline__ void fwd3_load_q(bf16x8 (&qf)[F3T][2], const AP& p, const Prob& pr, int wave, int lane) {
+__device__ __forceinline__ void fwd3_load_q(bf16x8 (&qf)[F3T][2], const AP& p, const Prob& pr, int wave, int lane, int tile0 = 0) {
   const bf16_t* qbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
 #pragma unroll
   for (int i = 0; i < F3T; ++i) {
-    const int rq = (wave + F3W * i) * 16 + (lane & 15);
+    const int rq = (tile0 + wave + F3W * i) * 16 + (lane & 15);
     load_row_frag(qf[i], qbase + (int64_t)tok_of(p, pr.n, rq < p.R ? rq : 0) * p.ldqkv, rq < p.R, lane >> 4);
   }
 }
@@ -372,10 +373,12 @@ __device__ __forceinline__ s16x4 frag_cols16_async(const char* tile, int dt, int
 // score (log2 e folded in), two independent partial sums.
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float M_INIT = -1e30f;
+// kb0: global key row of the staged group's first row (0 for single-group problems); corner: tile 0 of this wave holds the proxy
+// query rows AND the group holds the proxy keys (query block 0, wave 0, key group 0)
 template <int NS, int NTL, bool TAIL>
 __device__ __forceinline__ void fwd3_step(FwdState (&st)[F3T], const AP& p, int frame, const char* gK, const char* gV,
-                                          const bf16x8 (&qf)[F3T][2], int t0, int wave, int lane) {
-  const int g = lane >> 4, i16 = lane & 15, kb = t0 * 16;
+                                          const bf16x8 (&qf)[F3T][2], int t0, bool corner, int lane, int kb0 = 0) {
+  const int g = lane >> 4, i16 = lane & 15, kb = kb0 + t0 * 16;
   f32x4 s[NTL][NS];
   {
     bf16x8 kf[NS][2];
@@ -417,7 +420,7 @@ __device__ __forceinline__ void fwd3_step(FwdState (&st)[F3T], const AP& p, int 
         for (int r = 0; r < 4; ++r) s[i][t][r] = (16 * t + r < klim) ? s[i][t][r] : -INFINITY;
     }
     // proxy query rows meet proxy keys: counted in frame 0 only (CLIP_ViP.py:366-375 attends them once over all S keys)
-    if (i == 0 && t0 == 0 && wave == 0 && frame != 0) {
+    if (i == 0 && t0 == 0 && corner && frame != 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[0][0][r] = (i16 < p.M && 4 * g + r < p.M) ? -INFINITY : s[0][0][r];
     }
@@ -475,15 +478,15 @@ __device__ __forceinline__ void fwd3_problem(const AP& p, const Prob& pr, int pr
     st[i].m = M_INIT; st[i].l = 0.f;
   }
   int t0 = 0;
-  for (; t0 + 4 <= nsub && (t0 + 4) * 16 <= p.R; t0 += 4) fwd3_step<4, NTL, false>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+  for (; t0 + 4 <= nsub && (t0 + 4) * 16 <= p.R; t0 += 4) fwd3_step<4, NTL, false>(st, p, pr.n, gK, gV, qf, t0, wave == 0, lane);
   // the rest: 1..4 sub-tiles, the last of which may reach past R.  A 2- or 3-sub-tile rest runs the 4-wide step with its
   // surplus keys masked (rows < FG of the images are always written -- zeros past R -- and t0 <= 8 here)
   if (t0 < nsub) {
     if (nsub - t0 == 1) {
-      if (nsub * 16 > p.R) fwd3_step<1, NTL, true>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
-      else                 fwd3_step<1, NTL, false>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+      if (nsub * 16 > p.R) fwd3_step<1, NTL, true>(st, p, pr.n, gK, gV, qf, t0, wave == 0, lane);
+      else                 fwd3_step<1, NTL, false>(st, p, pr.n, gK, gV, qf, t0, wave == 0, lane);
     } else {
-      fwd3_step<4, NTL, true>(st, p, pr.n, gK, gV, qf, t0, wave, lane);
+      fwd3_step<4, NTL, true>(st, p, pr.n, gK, gV, qf, t0, wave == 0, lane);
     }
   }
 #pragma unroll
@@ -553,6 +556,125 @@ __global__ __launch_bounds__(F3THR, 2) void attn_fwd3_kernel(AP p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) qf[i][kk] = qn[i][kk];
     prob = next; cur ^= 1;
+  }
+}
+
+// ============================================================================================ forward, persistent, multi-group
+// Round 4: problems whose key window does not fit one LDS group (448^2 frames: R = 4 + 784 = 788 rows, BASELINE configs[3]).  The
+// 7-wave kernel gives every 112-row query block its own workgroup and each of them stages the whole K/V of the problem (8 x 202 KB per
+// problem, no overlap of staging and arithmetic inside a workgroup: 242 us per layer at configs[3], a quarter of its step).  Here the
+// structure of attn_fwd3_kernel is kept -- one persistent 8-wave workgroup per CU, K/V groups of up to 208 rows staged by LDS-DMA into
+// one of two 52 KiB buffers while the previous group is computed, two query tiles per wave sharing every K / V^T fragment read -- with
+// a work ITEM = (problem, block of 16 query tiles = 256 rows) and an inner walk over the problem's key groups with the online-softmax
+// state carried across them: K/V are staged ceil(tiles / 16) = 4 x per problem instead of 8 x, under the arithmetic.  The four blocks of
+// a problem run at the same step on four workgroups of ONE XCD (ids 8 apart), so three of the four K/V fetches are L2 hits; the
+// block roles rotate with the step so that the short last block (2 of 16 tiles at 788 rows) visits every workgroup equally.
+struct F4Stage { int prob, qb, kg; bool valid; };
+__device__ __forceinline__ F4Stage f4_stage(const AP& p, int s, int nqb, int ngrp) {
+  // stream position s of this workgroup: item = s / ngrp (one per step), key group = s % ngrp
+  F4Stage st;
+  const int step = s / ngrp;
+  st.kg = s - step * ngrp;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;              // block b runs on XCD b % 8 (speed only)
+  const int quads_per_xcd = ((int)gridDim.x >> 3) / nqb;             // workgroups of an XCD in groups of nqb
+  const int quad = j / nqb, role = j - quad * nqb;
+  st.qb = (role + step) % nqb;
+  st.prob = (step * quads_per_xcd + quad) * 8 + xcd;
+  st.valid = quad < quads_per_xcd && st.prob < p.nprob;
+  return st;
+}
+
+__global__ __launch_bounds__(F3THR, 2) void attn_fwd4_kernel(AP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = (p.R + 15) / 16;                     // sixteen-row tiles of a problem
+  const int nqb = (ntiles + 2 * F3W - 1) / (2 * F3W);     // query blocks of 16 tiles
+  const int ngrp = (ntiles + FG / 16 - 1) / (FG / 16);    // key groups of 13 sub-tiles
+  int s = 0, cur = 0;
+  F4Stage sg = f4_stage(p, 0, nqb, ngrp);
+  if (!sg.valid) return;                                  // (workgroups beyond the last whole quad of their XCD, or no problem left)
+  bf16x8 qf[F3T][2], qn[F3T][2];
+  {
+    const Prob pr(p, sg.prob);
+    fwd3_stage_kv(smem, smem + FG * 128, p, pr, lane, wave, 0);
+    fwd3_load_q(qf, p, pr, wave, lane, sg.qb * 2 * F3W);
+  }
+  FwdState st[F3T];
+  for (;;) {
+    __syncthreads();                                      // (vmcnt(0) + barrier) this stage's K/V landed; the other buffer is free
+    const Prob pr(p, sg.prob);
+    const F4Stage nx = f4_stage(p, s + 1, nqb, ngrp);
+    char* gK = smem + cur * F3_BUF;
+    if (nx.valid) {
+      const Prob pn(p, nx.prob);
+      char* nK = smem + (cur ^ 1) * F3_BUF;
+      fwd3_stage_kv(nK, nK + FG * 128, p, pn, lane, wave, nx.kg * FG);
+      if (nx.kg == 0) fwd3_load_q(qn, p, pn, wave, lane, nx.qb * 2 * F3W);
+    }
+    const int tile0 = sg.qb * 2 * F3W;
+    const int nt = tile0 + wave >= ntiles ? 0 : (tile0 + wave + F3W >= ntiles ? 1 : 2);       // this wave's query tiles in the item
+    if (sg.kg == 0) {
+#pragma unroll
+      for (int i = 0; i < F3T; ++i) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) st[i].o[dt] = f32x4{0, 0, 0, 0};
+        st[i].m = M_INIT; st[i].l = 0.f;
+      }
+    }
+    // the key steps of this group: ng sub-tiles starting at global key row kb0
+    const int kb0 = sg.kg * FG;
+    const int ng = ntiles - sg.kg * (FG / 16) < FG / 16 ? ntiles - sg.kg * (FG / 16) : FG / 16;
+    const bool corner = sg.qb == 0 && wave == 0 && sg.kg == 0;
+    auto run = [&](auto ntl_c) {
+      constexpr int NTL = decltype(ntl_c)::value;
+      int t0 = 0;
+      for (; t0 + 4 <= ng && kb0 + (t0 + 4) * 16 <= p.R; t0 += 4) fwd3_step<4, NTL, false>(st, p, pr.n, gK, gK + FG * 128, qf, t0, corner, lane, kb0);
+      if (t0 < ng) {
+        if (ng - t0 == 1) {
+          if (kb0 + ng * 16 > p.R) fwd3_step<1, NTL, true>(st, p, pr.n, gK, gK + FG * 128, qf, t0, corner, lane, kb0);
+          else                     fwd3_step<1, NTL, false>(st, p, pr.n, gK, gK + FG * 128, qf, t0, corner, lane, kb0);
+        } else {
+          fwd3_step<4, NTL, true>(st, p, pr.n, gK, gK + FG * 128, qf, t0, corner, lane, kb0);
+        }
+      }
+    };
+    if (nt == 2)      run(std::integral_constant<int, 2>{});
+    else if (nt == 1) run(std::integral_constant<int, 1>{});
+    if (sg.kg == ngrp - 1) {                               // last key group of the item: normalise and store
+#pragma unroll
+      for (int i = 0; i < F3T; ++i) {
+        if (i >= nt) continue;
+        const int rq = (tile0 + wave + F3W * i) * 16 + i16;
+        const float m = st[i].m;
+        const float l = group_sum(st[i].l);
+        if (rq >= p.R) continue;
+        if (rq < p.M) {
+          float* part = p.ws0 + ((int64_t)sg.prob * p.M + rq) * PART;
+          if (g == 0) { part[0] = m; part[1] = l; }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) store4(part + 2 + dt * 16 + 4 * g, st[i].o[dt]);
+          continue;
+        }
+        const int tok = tok_of(p, pr.n, rq);
+        const float inv = 1.0f / l;
+        bf16_t* orow = p.out + ((int64_t)pr.b * p.S + tok) * p.ldo + pr.h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + 4 * g, st[i].o[dt] * inv);
+        if (g == 0) {
+          float* sp = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok) * 2;
+          sp[0] = m; sp[1] = __logf(l);
+        }
+      }
+    }
+    if (!nx.valid) break;
+    if (nx.kg == 0) {
+#pragma unroll
+      for (int i = 0; i < F3T; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[i][kk] = qn[i][kk];
+    }
+    sg = nx; ++s; cur ^= 1;
   }
 }
 
@@ -1028,8 +1150,10 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   // the persistent kernel: proxy problems that fit one LDS group, no padding mask, at most 16 proxy rows (its proxy x proxy mask
   // lives in query tile 0 / key sub-tile 0 only), and a device that grants the 104 KiB dynamic-LDS opt-in (configured per device)
   bool use3 = fwd3 && mode == XP_ATTN_PROXY && p.R <= FG && p.M <= 16 && !pad_mask;
+  // the multi-group persistent kernel: proxy problems wider than one LDS group (448^2 frames), same conditions otherwise
+  bool use4 = fwd3 && mode == XP_ATTN_PROXY && p.R > FG && p.M <= 16 && !pad_mask;
   int ncu = 256;
-  if (use3) {
+  if (use3 || use4) {
     static std::mutex mu;
     static int configured[64] = {0};                  // per device -- 0: not yet, > 0: CU count, -1: refused
     int dev = 0;
@@ -1040,15 +1164,20 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
         int n = 256;
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            F3_LDS) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             F3_LDS) == hipSuccess;
         configured[dev] = ok ? (n > 0 ? n : 256) : -1;
       }
-      if (configured[dev] < 0) use3 = false; else ncu = configured[dev];
+      if (configured[dev] < 0) use3 = use4 = false; else ncu = configured[dev];
+      if (use4 && (ncu % 8 != 0 || ncu / 8 < (int)cdiv(cdiv(p.R, 16), 2 * F3W))) use4 = false;      // needs whole quads per XCD
     }
   }
   if (use3) {
     const int fgrid = fwd3 > 1 ? fwd3 : ncu;              // (XPRETRAIN_ATTN_FWD3=<n>: grid size, for experiments)
     attn_fwd3_kernel<<<(unsigned)(p.nprob < fgrid ? p.nprob : fgrid), F3THR, F3_LDS, st>>>(p);
+  } else if (use4) {
+    attn_fwd4_kernel<<<(unsigned)ncu, F3THR, F3_LDS, st>>>(p);      // persistent: one workgroup per CU (ncu is a multiple of 8 here)
   } else {
     attn_fwd_kernel<<<(unsigned)(cdiv(p.nprob, 8) * 8 * p.nq), FTHR, 0, st>>>(p);
   }
