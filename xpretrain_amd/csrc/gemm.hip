@@ -721,11 +721,10 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
                "(xp_gemm_colsum_rows() == 0): use xp_colsum / xp_colsum_partials");
   kp.tiles_m = (int)cdiv(d->M, BM); kp.tiles_n = (int)cdiv(d->N, BN);
   {
-    static const int gmax = getenv("XPRETRAIN_GEMM_GROUPN") ? atoi(getenv("XPRETRAIN_GEMM_GROUPN")) : 4;
+    const int gmax = 4;                   // L2 super-tile groups of <= 4 tile columns (A/B in round 2: profiles/r02_gemm256_ab_groupn_storepolicy.txt)
     const int ngroups = (int)cdiv(kp.tiles_n, gmax);
     kp.group_n = (int)cdiv(kp.tiles_n, ngroups);
-    static const int xr = getenv("XPRETRAIN_GEMM_NO_XCD") ? 0 : 1;
-    kp.xcd_remap = xr;
+    kp.xcd_remap = 1;
   }
   const int zsplits = (int)cdiv(d->K, kp.k_per_split);
   XP_REQUIRE(split == 1 || zsplits == split, "xp_gemm: split_k=%d leaves empty slabs for K=%lld (use <= %d)",

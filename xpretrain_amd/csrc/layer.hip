@@ -84,16 +84,10 @@ WgradSide* wgrad_side() {
   if (!w.side) {
     // The stream gets the device's HIGHEST priority: its few long GEMMs then claim CUs as soon as they are queued and the critical
     // chain's shorter kernels fill in around them (in-step A/B on one box, profiles/r04j_in_step_ab_wgrad_priority_split.txt:
-    // high 16.28, default 16.33, low 16.34 ms per step).  XPRETRAIN_WGRAD_PRIO=default|low: A/B switch.
-    const char* pr = getenv("XPRETRAIN_WGRAD_PRIO");
-    bool good;
-    if (pr && !strcmp(pr, "default")) {
-      good = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) == hipSuccess;
-    } else {
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      good = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, (pr && !strcmp(pr, "low")) ? least : greatest) == hipSuccess;
-    }
+    // highest 16.28, default 16.33, lowest 16.34 ms per step).
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    bool good = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, greatest) == hipSuccess;
     for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&w.ev[i], hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     w.ok = good;

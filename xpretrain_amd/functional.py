@@ -353,7 +353,7 @@ def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_ma
             g[name] = t
             setattr(a, name, t.data_ptr())
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    if side is not None and side_x2 is not None and os.environ.get("XPRETRAIN_LN_BWD_SIDE", "1") != "0":   # the forward's fp32 side rows of x and x2: read by the LayerNorm backward passes
+    if side is not None and side_x2 is not None:          # the forward's fp32 side rows of x and x2: read by the LayerNorm backward passes
         a.side_in, a.side_x2 = side.data_ptr(), side_x2.data_ptr()
         a.side_S, a.side_M = (plan.dims.S, plan.dims.M) if plan.dims.attn_mode == L.ATTN_PROXY else (1, 1)
     L.check(L.lib().xp_encoder_layer_bwd(C.byref(a), H._stream()), "xp_encoder_layer_bwd")
