@@ -368,6 +368,63 @@ def test_gradient_checkpointing_recomputes_bit_identically():
     print(f"peak memory without / with checkpointing: {m0 / 2**20:.0f} / {m1 / 2**20:.0f} MiB (tiny model: cached workspaces dominate)")
 
 
+@pytest.mark.parametrize("shape", ["tiny", "vit_b_2layers"])
+def test_forward_as_two_half_batch_chains_is_bit_identical(monkeypatch, shape):
+    """functional.ForwardSplit: the video tower's training forward as two half-batch chains on two streams writes the same full-batch
+    buffers with the same kernels per row -- features, loss and every gradient are bit-identical to the single chain, repeatedly
+    (a race between the chains would show as a run-to-run difference)."""
+    import xpretrain_amd.functional as XF
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import NCELearnableTempLoss
+    torch.manual_seed(11)
+    if shape == "tiny":
+        cfgd = O.hf_config_dict(128, 2, 4, 256, 16, 32, 128, 2, 3, 256, 120, 16, 64)
+        model = VidCLIP(_Args(cfgd, 3)).cuda().train()
+        inputs = O.synthetic_inputs(4, 3, 32, 12, vocab=120)
+    else:
+        cfgd = O.vit_b_config(16, 224)
+        cfgd["vision_config"]["num_hidden_layers"] = 2
+        cfgd["text_config"]["num_hidden_layers"] = 1
+        model = VidCLIP(_Args(cfgd, 12)).cuda().train()
+        inputs = O.synthetic_inputs(4, 12, 224, 32, seed=5)
+    video, ids, mask = (t.cuda() for t in inputs)
+    monkeypatch.setattr(XF, "FWD_SPLIT_MIN_ROWS", 0)
+    made = []
+    real = XF.ForwardSplit
+
+    class Spy(real):
+        def __init__(self, device):
+            made.append(1)
+            super().__init__(device)
+    monkeypatch.setattr(XF, "ForwardSplit", Spy)
+
+    def run(on):
+        monkeypatch.setattr(XF, "FWD_SPLIT", on)
+        for p in model.parameters():
+            p.grad = None
+        out = model(video, ids, mask)
+        loss = NCELearnableTempLoss()(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out["vis_features"].detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}
+    v0, l0, g0 = run(False)
+    assert not made
+    for rep in range(3):
+        v1, l1, g1 = run(True)
+        assert len(made) == rep + 1
+        assert torch.equal(v0, v1) and torch.equal(l0, l1)
+        bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+        assert not bad, bad[:5]
+    with torch.no_grad():               # forward-only passes: two chains as well (freed buffers wait for the second chain)
+        monkeypatch.setattr(XF, "FWD_SPLIT", False)
+        f0 = model(video, ids, mask)["vis_features"].clone()
+        monkeypatch.setattr(XF, "FWD_SPLIT", True)
+        for rep in range(3):
+            f1 = model(video, ids, mask)["vis_features"]
+            assert torch.equal(f0, f1)
+    assert len(made) == 6
+
+
 def test_inference_forward_gathers_patches_in_the_gemm(monkeypatch):
     """torch.no_grad() / frozen patch embedding: VisionEmbedFn lets the GEMM loader gather the patches (no im2col pass, no patch
     matrix); the features are bit-identical to the materialised path, for fp32 and uint8 frames; a training pass still materialises

@@ -360,12 +360,13 @@ bool xp_gemm256_legal(const XpGemmDesc* d) {
   return epi_supported(d);
 }
 
-// XPRETRAIN_GEMM256: 0 = never, 1 = when it fills at least half the CUs (default), 2 = whenever legal.
+// XPRETRAIN_GEMM256: 0 = never, 1 = from 96 workgroups (default: a half-batch N = 768 GEMM of the forward's two chains is 111 tiles and
+// runs beside its twin), 2 = whenever legal.
 bool xp_gemm256_wanted(const XpGemmDesc* d, int split) {
   const char* env = getenv("XPRETRAIN_GEMM256");
   const int mode = env ? atoi(env) : 1;
   if (mode == 0 || !xp_gemm256_legal(d)) return false;
-  if (mode == 1 && cdiv(d->M, TM) * cdiv(d->N, TN) * split < 128) return false;
+  if (mode == 1 && cdiv(d->M, TM) * cdiv(d->N, TN) * split < 96) return false;
   return true;
 }
 

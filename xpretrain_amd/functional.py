@@ -12,6 +12,7 @@ Reference call sites are cited per class (paths relative to /root/reference/CLIP
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import weakref
@@ -43,6 +44,7 @@ class WeightCache:
         self._c = {}
         self.generation = 0
         self.structure_version = 0      # bumped whenever a cached buffer is (re)allocated
+        self.casts = 0                  # bumped whenever a cast kernel is launched (on the caller's current stream)
         self._hooked = False
 
     def _ensure_hook(self):
@@ -100,6 +102,7 @@ class WeightCache:
             buf = ent.buf if reuse else torch.empty(shape, dtype=dtype, device=ws[0].device)
             if reuse:
                 torch.autograd.graph.increment_version(buf)      # in-place rewrite below (raw pointer): see invalidate()
+            self.casts += 1
             if _single:
                 H.cast(ws[0].detach(), dtype, out=buf)
             else:
@@ -172,6 +175,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, 
 # op-by-op path (tools/determinism_hunt.py fingerprints every call of it; tests compare the two paths bit for bit).
 LAYER_CALLS = os.environ.get("XPRETRAIN_LAYER_CALLS", "1") != "0"
 _DT_CODE = {torch.bfloat16: L.XP_BF16, torch.float32: L.XP_F32}
+_NULLCTX = contextlib.nullcontext()
 _ES = {torch.bfloat16: 2, torch.float32: 4}
 _PLANS = {}
 
@@ -245,32 +249,81 @@ def _native_ok(x, vecs, mats, pad_mask) -> bool:
     return True
 
 
-def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True, side=None):
+# XPRETRAIN_FWD_SPLIT=0: the whole batch as one chain (A/B switch for the two half-batch chains of the video tower's forward)
+FWD_SPLIT = os.environ.get("XPRETRAIN_FWD_SPLIT", "1") != "0"
+FWD_SPLIT_MIN_ROWS = 8192          # below this a half-batch launch no longer fills the chip beside its twin
+_SPLIT_STREAMS = {}
+
+
+class ForwardSplit:
+    """The video tower's training forward as TWO half-batch chains: samples are independent in the forward, every kernel of a layer
+    is row-parallel (GEMM rows, LayerNorm rows, attention per sample), so the second half of the batch runs the same layer call on a
+    second stream into the second half of the SAME full-batch buffers.  The chains never wait for each other between layers: one
+    chain's HBM-bound kernels (LayerNorm, attention, GEMM epilogues) run beside the other's MFMA main loops, and each chain's 111- /
+    333- / 444-tile GEMMs fill the CUs the other leaves idle.  The backward sees ordinary full-batch buffers.  Results are bit-identical
+    to the single chain (the same kernels compute every row).  Forward-only passes free a layer's buffers while the second chain may
+    still be reading them: those are handed to the caching allocator with ``record_stream`` (reuse waits for the chain).
+    Measured: profiles/r04r_split_batch_probe_gemm256_forced.txt (probe), r04s_ab_fwd_split.txt (the step: -0.45 ms)."""
+
+    def __init__(self, device):
+        st = _SPLIT_STREAMS.get(device.index)
+        if st is None:
+            st = _SPLIT_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        self.stream = st
+        self.main = torch.cuda.current_stream(device)
+        self.stream.wait_stream(self.main)          # fork: everything the tower's input depends on
+
+    def join(self):
+        self.main.wait_stream(self.stream)
+
+
+def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True, side=None,
+                      split=None):
     dev = x.device
     arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
     x3 = torch.empty_like(x)
-    ws = H.workspace(plan.fwd_ws, dev, "layer_fwd")
-    a = L.XpLayerFwd()
-    a.dims = plan.dims
-    a.x, a.Wqkv, a.Wo, a.W1, a.W2 = x.data_ptr(), Wqkv.data_ptr(), Wo.data_ptr(), W1.data_ptr(), W2.data_ptr()
-    a.ln1_w, a.ln1_b, a.bqkv, a.bo = ln1_w.data_ptr(), ln1_b.data_ptr(), bqkv.data_ptr(), bo.data_ptr()
-    a.ln2_w, a.ln2_b, a.b1, a.b2 = ln2_w.data_ptr(), ln2_b.data_ptr(), b1.data_ptr(), b2.data_ptr()
-    a.pad_mask = 0 if pad_mask is None else pad_mask.data_ptr()
-    base, off = arena.data_ptr(), plan.off
-    a.h1, a.qkv, a.attn_o, a.x2, a.h2 = base + off["h1"], base + off["qkv"], base + off["attn_o"], base + off["x2"], base + off["h2"]
-    a.pre, a.act, a.x3 = (base + off["pre"]) if keep_pre else 0, base + off["act"], x3.data_ptr()
-    a.mean1, a.rstd1, a.mean2, a.rstd2 = base + off["mean1"], base + off["rstd1"], base + off["mean2"], base + off["rstd2"]
-    a.stats = base + off["stats"]
-    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     side_out = side_x2 = None
     if side is not None:
         side_out = torch.empty_like(side)
-        a.side_in, a.side_out = side.data_ptr(), side_out.data_ptr()
-        a.side_S, a.side_M = (plan.dims.S, plan.dims.M) if plan.dims.attn_mode == L.ATTN_PROXY else (1, 1)
         if keep_pre:            # training pass: the x2 side rows are kept for the backward's second LayerNorm
             side_x2 = torch.empty_like(side)
-            a.side_x2 = side_x2.data_ptr()
-    L.check(L.lib().xp_encoder_layer_fwd(C.byref(a), H._stream()), "xp_encoder_layer_fwd")
+    d = plan.dims
+    es, D, Dff = _ES[x.dtype], d.D, d.Dff
+    base, off = arena.data_ptr(), plan.off
+    video = d.attn_mode == L.ATTN_PROXY
+    if split is None:
+        parts = [(plan, 0, 0, None)]
+    else:                       # two half-batch chains: (plan of half the batch, first row, first sample, stream)
+        hp = _layer_plan(d.rows // 2, D, Dff, d.B // 2, d.S, d.heads, (d.M, d.N, d.L), x.dtype)
+        parts = [(hp, 0, 0, None), (hp, d.rows // 2, d.B // 2, split.stream)]
+    for pl, r0, b0, stream in parts:
+        with (torch.cuda.stream(stream) if stream is not None else _NULLCTX):
+            ws = H.workspace(pl.fwd_ws, dev, "layer_fwd")          # (per stream)
+            a = L.XpLayerFwd()
+            a.dims = pl.dims
+            a.x, a.Wqkv, a.Wo, a.W1, a.W2 = x.data_ptr() + r0 * D * es, Wqkv.data_ptr(), Wo.data_ptr(), W1.data_ptr(), W2.data_ptr()
+            a.ln1_w, a.ln1_b, a.bqkv, a.bo = ln1_w.data_ptr(), ln1_b.data_ptr(), bqkv.data_ptr(), bo.data_ptr()
+            a.ln2_w, a.ln2_b, a.b1, a.b2 = ln2_w.data_ptr(), ln2_b.data_ptr(), b1.data_ptr(), b2.data_ptr()
+            a.pad_mask = 0 if pad_mask is None else pad_mask.data_ptr()
+            rD, rF = r0 * D * es, r0 * Dff * es
+            a.h1, a.qkv, a.attn_o = base + off["h1"] + rD, base + off["qkv"] + 3 * rD, base + off["attn_o"] + rD
+            a.x2, a.h2 = base + off["x2"] + rD, base + off["h2"] + rD
+            a.pre, a.act, a.x3 = (base + off["pre"] + rF) if keep_pre else 0, base + off["act"] + rF, x3.data_ptr() + rD
+            a.mean1, a.rstd1 = base + off["mean1"] + r0 * 4, base + off["rstd1"] + r0 * 4
+            a.mean2, a.rstd2 = base + off["mean2"] + r0 * 4, base + off["rstd2"] + r0 * 4
+            a.stats = base + off["stats"] + b0 * d.heads * d.S * 2 * 4
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            if side is not None:
+                so = (b0 * d.M if video else r0) * D * 4          # side rows: [B*M, D] (video) / [rows, D] (text), fp32
+                a.side_in, a.side_out = side.data_ptr() + so, side_out.data_ptr() + so
+                a.side_S, a.side_M = (d.S, d.M) if video else (1, 1)
+                if side_x2 is not None:
+                    a.side_x2 = side_x2.data_ptr() + so
+            L.check(L.lib().xp_encoder_layer_fwd(C.byref(a), H._stream()), "xp_encoder_layer_fwd")
+    if split is not None and not keep_pre:      # forward-only pass: these die before the chains are joined
+        for t in (x, arena, x3, side, side_out):
+            if t is not None:
+                t.record_stream(split.stream)
     return x3, arena, side_out, side_x2
 
 
@@ -364,7 +417,7 @@ def _layer_bwd_native(ctx, dx3, x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_ma
     return (dx, g.get("dln1_w"), g.get("dln1_b"),
             pick(dwqkv, 0, need[3]), pick(dbqkv, 0, need[4]), pick(dwqkv, 1, need[5]), pick(dbqkv, 1, need[6]),
             pick(dwqkv, 2, need[7]), pick(dbqkv, 2, need[8]), gw("dwo", (D, D)), g.get("dbo"), g.get("dln2_w"), g.get("dln2_b"),
-            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None, None, None)
+            gw("dw1", (Dff, D)), g.get("db1"), gw("dw2", (D, Dff)), g.get("db2"), None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ encoder layer
@@ -376,7 +429,7 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2,
                 B: int, S: int, heads: int, size: Optional[Tuple[int, int, int]], pad_mask: Optional[torch.Tensor],
-                training: bool = True, side: Optional[torch.Tensor] = None):
+                training: bool = True, side: Optional[torch.Tensor] = None, split: Optional["ForwardSplit"] = None):
         """``side`` (fp32, bf16 compute only): the fp32 side rows of ``x`` (SideRows, csrc/gemm_common.h) -- [B*M, D], the proxy rows of
         every sample, in the video tower; [B*S, D], the whole stream, in the text tower.  The call then returns ``(x3, side_out)``."""
         dt = x.dtype
@@ -389,13 +442,18 @@ class EncoderLayerFn(torch.autograd.Function):
         if dh != 64:
             raise RuntimeError(f"xpretrain_amd attention kernels are built for head_dim 64, got {dh}")
         q_scale = dh ** -0.5
+        casts0 = WEIGHTS.casts
         Wqkv = WEIGHTS.fused((wq, wk, wv), dt)
         bqkv = WEIGHTS.fused((bq, bk, bv), torch.float32)
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
         if LAYER_CALLS and _native_ok(x, (ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2), (Wqkv, Wo, W1, W2), pad_mask):
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
+            if split is not None and (size is None or B % 2 or pad_mask is not None):
+                split = None
+            if split is not None and WEIGHTS.casts != casts0:       # a weight copy was (re)made on this stream just now: the second
+                split.stream.wait_stream(torch.cuda.current_stream())   # chain must not read it before the cast has run
             x3, arena, side_out, side_x2 = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan,
-                                                             pad_mask, keep_pre=training, side=side)
+                                                             pad_mask, keep_pre=training, side=side, split=split)
             ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, side, side_x2)
             ctx.plan = plan
             if GRAD_SINKS:          # (data-parallel runs only) the layer's parameters in the flat gradient order
@@ -439,7 +497,7 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx3, _dside=None):
         if dx3 is None:             # (set_materialize_grads(False): the layer output did not reach the loss)
-            return (None,) * 24
+            return (None,) * 25
         if ctx.plan is not None:
             x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, side, side_x2 = ctx.saved_tensors
             if dx3.dtype != x.dtype or dx3.device != x.device or dx3.shape != x.shape:
@@ -493,7 +551,7 @@ class EncoderLayerFn(torch.autograd.Function):
         defer.flush()
         keep = lambda i, g: g if need[i] else None          # (LayerNorm parameter / out_proj bias sums ride on passes that run anyway)
         return (dx, keep(1, dln1_w), keep(2, dln1_b), dwq, dbq, dwk, dbk, dwv, dbv, dwo, keep(10, dbo), keep(11, dln2_w),
-                keep(12, dln2_b), dw1, db1, dw2, keep(16, db2), None, None, None, None, None, None, None)
+                keep(12, dln2_b), dw1, db1, dw2, keep(16, db2), None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ fp32 side rows (proxy tokens)
@@ -743,8 +801,8 @@ def _layer_params(layer):
     return tuple(d[k] for d in tabs for k in ("weight", "bias"))
 
 
-def encoder_layer(x, layer, B, S, heads, size, pad_mask, side=None):
+def encoder_layer(x, layer, B, S, heads, size, pad_mask, side=None, split=None):
     """Apply ``EncoderLayerFn`` with the parameters of a ``CLIPEncoderLayer`` module.  With ``side`` (the proxy rows of x in fp32)
-    returns ``(x3, side_out)``."""
+    returns ``(x3, side_out)``.  ``split``: a ``ForwardSplit`` (the tower runs as two half-batch chains)."""
     # `training` argument: forward-only passes (torch.no_grad: retrieval / inference) skip the MLP pre-activation
-    return EncoderLayerFn.apply(x, *_layer_params(layer), B, S, heads, size, pad_mask, torch.is_grad_enabled(), side)
+    return EncoderLayerFn.apply(x, *_layer_params(layer), B, S, heads, size, pad_mask, torch.is_grad_enabled(), side, split)

@@ -218,8 +218,8 @@ class CLIPEncoderLayer(nn.Module):
         self.mlp = CLIPMLP(config)
         self.layer_norm2 = nn.LayerNorm(self.embed_dim)
 
-    def forward(self, hidden_states, B, S, inputs_size=None, pad_mask=None, side=None):
-        return XF.encoder_layer(hidden_states, self, B, S, self.num_heads, inputs_size, pad_mask, side)
+    def forward(self, hidden_states, B, S, inputs_size=None, pad_mask=None, side=None, split=None):
+        return XF.encoder_layer(hidden_states, self, B, S, self.num_heads, inputs_size, pad_mask, side, split)
 
 
 class CLIPEncoder(nn.Module):
@@ -236,6 +236,11 @@ class CLIPEncoder(nn.Module):
         ``collect`` / ``collect_side``: lists that receive every layer output (compute dtype, as ``last_hidden_state``) and its
         fp32 side rows (``output_hidden_states``)."""
         ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        # video tower: two half-batch chains on two streams (functional.ForwardSplit), joined after the last layer
+        split = None
+        if (XF.FWD_SPLIT and XF.LAYER_CALLS and inputs_size is not None and pad_mask is None and not ckpt
+                and x.is_cuda and B % 2 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS):
+            split = XF.ForwardSplit(x.device)
         for layer in self.layers:
             if ckpt:
                 # reference CLIP_ViP.py:675-690 (torch.utils.checkpoint around every encoder layer): the layer's saved-activation
@@ -247,13 +252,15 @@ class CLIPEncoder(nn.Module):
                 else:
                     x, side = checkpoint(lambda t, sd, _l=layer: _l(t, B, S, inputs_size, pad_mask, sd), x, side, use_reentrant=False)
             elif side is None:
-                x = layer(x, B, S, inputs_size, pad_mask)
+                x = layer(x, B, S, inputs_size, pad_mask, None, split)
             else:
-                x, side = layer(x, B, S, inputs_size, pad_mask, side)
+                x, side = layer(x, B, S, inputs_size, pad_mask, side, split)
             if collect is not None:
                 collect.append(x)
                 if collect_side is not None and side is not None:
                     collect_side.append(side)
+        if split is not None:
+            split.join()
         return x if side is None else (x, side)
 
 
