@@ -287,6 +287,13 @@ def main():
         return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # probe switch (tools/instep_ab.py): a ONE-rank RCCL group with the collectives forced on -- the feature gather and the bucket
+    # all-reduces go through the process group's stream and events as in a data-parallel run (no bytes leave the GPU); marked in the line
+    fmode = os.environ.get("XPRETRAIN_BENCH_FORCE_COLLECTIVES", "")          # "1" | "gather" | "reducer" (cost attribution)
+    forced = W == 1 and fmode in ("1", "gather", "reducer")
+    if forced:
+        torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", world_size=1, rank=0)
+        D.FORCE_COLLECTIVES = True
     cu_budget = D.reserve_cus_for_collectives()          # 256 in a 1-rank run
 
     from oracle import clipvip_oracle as O          # input generator + FLOP model only (not on the timed path)
@@ -303,8 +310,11 @@ def main():
     loss_fn = NCELearnableTempLoss()
     import xpretrain_amd.functional as XF
     # buckets aligned to the encoder layers: the native layer backward writes its gradients straight into bucket storage
-    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=64.0, average=True, layout_groups=XF.layer_grad_groups(model),
+    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=float(os.environ.get("XPRETRAIN_BENCH_BUCKET_MB", "64")), average=True,
+                                  layout_groups=XF.layer_grad_groups(model), segments=D.tower_segments(model),
                                   wire_dtype={"fp32": None, "bf16": torch.bfloat16}[os.environ.get("XPRETRAIN_GRAD_WIRE", "fp32")])
+    if forced and fmode == "gather":        # the gradient reducer stays out of it
+        reducer.remove(); reducer._active = False
     use_graph = a.graph == 1
     # pretrain_vip_base_16.json:68-80: adamw, betas (0.9, 0.98), lr 5e-6, wd 0.05, lr_mul 1, cosine decay with 1 % warmup,
     # grad_norm 5.0; grouping = optimization/utils.py:124-154
@@ -322,7 +332,10 @@ def main():
         with torch.no_grad():
             logit_scale.clamp_(0, math.log(200.0))                       # run_pretrain.py:335-340
         out = model(video, ids, mask)
-        vis, txt = D.gather_features(out["vis_features"], out["text_features"])
+        if forced and fmode == "reducer":    # the feature gather stays out of it
+            vis, txt = out["vis_features"], out["text_features"]
+        else:
+            vis, txt = D.gather_features(out["vis_features"], out["text_features"])
         loss = loss_fn(vis, txt, logit_scale)
         loss.backward()
         reducer.synchronize()
@@ -464,7 +477,9 @@ def main():
                                    f"local batch {a.batch}, " + workload_tag(a, W),
                        "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4),
                        "gemm_cu_budget": cu_budget, "grad_wire": os.environ.get("XPRETRAIN_GRAD_WIRE", "fp32"),
+                       "forced_one_rank_collectives": forced,
                        "video_forward_chains": 2 if two_chains else 1,
+                       "second_chain_stream": XF.second_chain_stream_mode() if two_chains else None,
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager"},
             "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
             "step_frac_of_bf16_peak": round(step_flops / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -499,7 +514,7 @@ def main():
         if not a.no_cpu_baseline and W == 1:           # reported baseline, rank 0 of the single-GPU run only
             res["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(res), flush=True)
-    if W > 1:
+    if W > 1 or forced:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

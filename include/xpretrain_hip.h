@@ -384,6 +384,11 @@ typedef struct XpLayerBwd {
 } XpLayerBwd;
 size_t xp_encoder_layer_bwd_workspace_bytes(const XpLayerDims* dims);
 int xp_encoder_layer_bwd(const XpLayerBwd* args, void* stream);
+/* The library's second stream of the current device (the one xp_encoder_layer_bwd issues the weight-gradient GEMMs on; created at the
+ * device's highest priority on first use), or NULL when XPRETRAIN_WGRAD_STREAM=0.  It is idle outside xp_encoder_layer_bwd calls: the
+ * host side runs the second half-batch chain of the video tower's forward on it instead of creating one more stream (a process gets few
+ * hardware queues). */
+void* xp_side_stream(void);
 
 /* -------------------------------------------------------------------------------------- Diagnostics
  * Hardware-layout probes used by tests/test_probe_gpu.py to pin the MFMA / LDS-transpose lane maps

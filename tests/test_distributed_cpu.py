@@ -200,7 +200,7 @@ def _layout_worker(rank, world, port, q):
                 sink[off:off + p.numel()] = (rank + 1) * torch.arange(p.numel(), dtype=torch.float32) + p.numel()
                 p.grad = sink[off:off + p.numel()].view_as(p)
                 off += p.numel()
-                red._on_grad(p)
+            red._on_group(g[0])                                # ONE hook per group (its first parameter), credited at the next hook
             views = {id(q): v for q, v in zip(b["params"], b["views"])}
             ok = ok and all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in g)
         for p in (ps[2], ps[5]):                               # parameters outside any group: the usual adopted tensors
@@ -219,6 +219,92 @@ def _layout_worker(rank, world, port, q):
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _ThreeParamLayer(torch.autograd.Function):
+    """stand-in for functional.EncoderLayerFn: ONE autograd node that returns the gradients of all its parameters together"""
+
+    @staticmethod
+    def forward(ctx, x, a, b, c):
+        ctx.save_for_backward(x, a, b, c)
+        return x * a + b + c.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a, b, c = ctx.saved_tensors
+        return g * a, g * x, g.clone(), g.sum() * torch.ones_like(c)
+
+
+def _group_hook_worker(rank, world, port, q):
+    """The reducer registers ONE hook per layout group and credits the group at the next hook: run through the REAL autograd engine
+    (a chain of one-node layers, a layer applied twice, loose parameters before / between / after), buckets of about one layer,
+    against the plain per-parameter averaging."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from xpretrain_amd import distributed as D
+    D.init_from_env("gloo")
+    torch.manual_seed(0)
+    n, L = 6, 5
+    layers = [[torch.nn.Parameter(torch.randn(n)), torch.nn.Parameter(torch.randn(n)), torch.nn.Parameter(torch.randn(3))] for _ in range(L)]
+    head, mid, tail = (torch.nn.Parameter(torch.randn(n)) for _ in range(3))
+    params = [head] + [p for lay in layers[:2] for p in lay] + [mid] + [p for lay in layers[2:] for p in lay] + [tail]
+    groups = [[lay[1], lay[0], lay[2]] for lay in layers]                 # group order != argument order
+
+    def loss_of(x):
+        h = x * head
+        for i, (a, b, c) in enumerate(layers):
+            h = _ThreeParamLayer.apply(h, a, b, c)
+            if i == 1:
+                h = h + mid
+                h = _ThreeParamLayer.apply(h, *layers[0])               # layer 0 applied a second time
+        return (h * tail).sum()
+    torch.manual_seed(100)
+    xs = [torch.randn(n) * (r + 1) for r in range(world)]                # (every rank can build every rank's input)
+    want = None
+    for r in range(world):
+        for p in params:
+            p.grad = None
+        loss_of(xs[r]).backward()
+        g = [p.grad.clone() for p in params]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    want = [w / world for w in want]
+    for p in params:
+        p.grad = None
+    segs = [params[:8], params[8:]]                                        # a bucket never spans two segments
+    red = D.GradBucketReducer(params, bucket_mb=4 * (2 * n + 3) / (1 << 20), average=True, layout_groups=groups, segments=segs)
+    ok = len(red._hooks) == L + 3 and len(red.buckets) >= 3
+    first = {id(p) for p in segs[0]}
+    ok = ok and all(len({id(p) in first for p in b["params"]}) == 1 for b in red.buckets)
+    for step in range(2):                                               # two steps: the pending state resets
+        loss_of(xs[rank]).backward()
+        launched = sum(b["work"] is not None for b in red.buckets)
+        red.synchronize()
+        ok = ok and launched >= len(red.buckets) - 2                    # all but the last bucket(s) left during backward
+        ok = ok and all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(params, want))
+        red.zero_grad()
+    # gradient accumulation: first micro-step under no_sync
+    with red.no_sync():
+        loss_of(xs[rank]).backward()
+    loss_of(xs[rank]).backward()
+    red.synchronize()
+    ok = ok and all(torch.allclose(p.grad, 2 * w, rtol=1e-5, atol=1e-6) for p, w in zip(params, want))
+    red.zero_grad(); red.remove()
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_group_hooks_through_the_autograd_engine():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_hook_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
 
 
 def test_layout_groups_and_gradient_sinks():

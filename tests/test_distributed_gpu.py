@@ -41,7 +41,8 @@ def test_one_rank_nccl_group_matches_plain_step():
         model = VidCLIP(_Args(cfgd, 2)).cuda().train()
         D.broadcast_parameters(model)
         reducer = D.GradBucketReducer(model.parameters(), bucket_mb=0.25, average=True,     # several buckets
-                                      layout_groups=XF.layer_grad_groups(model) if sinks else None, wire_dtype=wire)
+                                      layout_groups=XF.layer_grad_groups(model) if sinks else None, wire_dtype=wire,
+                                      segments=D.tower_segments(model) if sinks else None)
         assert reducer._active == distributed
         if sinks:
             assert len(XF.GRAD_SINKS) == 4            # 2 video + 2 text layers publish a gradient sink each
@@ -74,7 +75,8 @@ def test_one_rank_nccl_group_matches_plain_step():
         torch.manual_seed(5)
         model = VidCLIP(_Args(cfgd, 2)).cuda().train()
         reducer = D.GradBucketReducer(model.parameters(), bucket_mb=0.25, average=True,
-                                      layout_groups=XF.layer_grad_groups(model) if sinks else None)
+                                      layout_groups=XF.layer_grad_groups(model) if sinks else None,
+                                      segments=D.tower_segments(model) if sinks else None)
         video, ids, mask = batch
         image = video[:, :1].contiguous()
         cap_ids, cap_mask = ids.flip(0).contiguous().view(-1, 1, ids.shape[1]), mask.flip(0).contiguous().view(-1, 1, mask.shape[1])

@@ -65,6 +65,28 @@ def timed(f, n):
 
 base = timed(step, steps)
 print(f"step alone: {base:.3f} ms")
+# how many streams can the step touch before the runtime's stream -> hardware-queue mapping bites?  (main, second forward chain, text
+# tower, weight-gradient stream are in use already; a collective adds at least one.)  Extra streams that do NOTHING but an event
+# hand-shake with the main stream at the start of backward:
+import os  # noqa: E402
+for n_extra in [int(x) for x in os.environ.get("PROBE_EXTRA_STREAMS", "").split(",") if x]:
+    extra = [torch.cuda.Stream(device=dev) for _ in range(n_extra)]
+
+    def step_touch():
+        with torch.no_grad():
+            ls.clamp_(0, math.log(200.0))
+        out = model(video, ids, mask)
+        loss = loss_fn(out["vis_features"], out["text_features"], ls)
+        main = torch.cuda.current_stream()
+        for st in extra:
+            st.wait_stream(main)
+        loss.backward()
+        for st in extra:
+            main.wait_stream(st)
+        opt.clip_and_step(5.0)
+        reducer.zero_grad()
+    t = timed(step_touch, steps)
+    print(f"step with {n_extra} extra idle stream(s) forked at the start of backward and joined after it: {t:.3f} ms ({t - base:+.3f} ms)")
 # "thin": a copy kernel with a handful of registers (fits beside a GEMM workgroup's waves); "rccl footprint": the same copy in a
 # kernel with the resources of RCCL's gfx950 collective kernel (csrc/probe.hip: 288 registers per lane = one wave per SIMD, 19,744 B
 # LDS) -- it cannot share a CU with a 256x256-GEMM workgroup, so its workgroups take whole CUs away from the GEMMs for as long as

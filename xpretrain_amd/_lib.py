@@ -147,6 +147,7 @@ SIGNATURES = {
     "xp_encoder_layer_fwd": (i32, [C.POINTER(XpLayerFwd), vp]),
     "xp_encoder_layer_bwd_workspace_bytes": (sz, [C.POINTER(XpLayerDims)]),
     "xp_encoder_layer_bwd": (i32, [C.POINTER(XpLayerBwd), vp]),
+    "xp_side_stream": (vp, []),
     "xp_debug_set_gemm_trace": (i32, [vp]),
     "xp_debug_gemm_timer_arm": (i32, [i64, i64, i64, i32, i32, i32, i32, i32]),
     "xp_debug_gemm_timer_read": (i32, [C.POINTER(C.c_float), i32]),

@@ -82,12 +82,11 @@ WgradSide* wgrad_side() {
   std::lock_guard<std::mutex> lock(mu);
   WgradSide& w = per_dev[dev];
   if (!w.side) {
-    // The stream gets the device's HIGHEST priority: its few long GEMMs then claim CUs as soon as they are queued and the critical
-    // chain's shorter kernels fill in around them (in-step A/B on one box, profiles/r04j_in_step_ab_wgrad_priority_split.txt:
-    // highest 16.28, default 16.33, lowest 16.34 ms per step).
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    bool good = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, greatest) == hipSuccess;
+    // DEFAULT priority.  Highest priority was worth 0.05 ms per step on one GPU (profiles/r04j_in_step_ab_wgrad_priority_split.txt) and
+    // cost 15-30 ms per step as soon as a process group's collectives ran beside it (a ONE-rank RCCL group on one GPU: 36-52 ms per
+    // step against 21 with the default priority, profiles/r04v_forced_one_rank_collectives_stream_matrix.txt) -- a high-priority HSA
+    // queue beside the collective library's streams starves the queues the critical chain runs on.
+    bool good = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, 0) == hipSuccess;
     for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&w.ev[i], hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     w.ok = good;
@@ -103,6 +102,11 @@ int check_dims(const char* name, const XpLayerDims& d) {
 }
 
 }  // namespace
+
+extern "C" void* xp_side_stream(void) {
+  WgradSide* w = wgrad_side();
+  return w ? (void*)w->side : nullptr;
+}
 
 extern "C" size_t xp_encoder_layer_fwd_workspace_bytes(const XpLayerDims* d) {
   if (!d) return 0;

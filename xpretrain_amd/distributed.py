@@ -122,6 +122,15 @@ def gather_features(vis: torch.Tensor, txt: torch.Tensor, verify_identical: bool
     return gather_packed(vis, txt, verify_identical=verify_identical)
 
 
+# XPRETRAIN_DEBUG_REDUCER=nocomm: the reducer packs and tracks its buckets but skips the all-reduce calls (cost attribution on one GPU)
+_DEBUG_NO_COMM = os.environ.get("XPRETRAIN_DEBUG_REDUCER", "") == "nocomm"
+
+
+class _NoWork:
+    def wait(self):
+        return True
+
+
 class GradBucketReducer:
     """Bucketed, backward-overlapped gradient all-reduce (the role of hvd.DistributedOptimizer + synchronize()).
 
@@ -137,14 +146,17 @@ class GradBucketReducer:
     ``no_sync`` before ``synchronize()`` is an error (the in-flight collective would miss its contribution) and raises."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, average: bool = True,
-                 group=None, layout_groups=None, wire_dtype=None):
+                 group=None, layout_groups=None, wire_dtype=None, segments=None):
         """``layout_groups``: lists of parameters that must sit contiguously, in the given order, inside one bucket -- the flat
         gradient layout a producer writes in one piece (``functional.layer_grad_groups(model)``: the 16 parameters of an encoder
         layer in the order of the native layer backward's flat buffer).  With it the bucket storage is allocated up front and
         published through ``functional.GRAD_SINKS``: the layer backward writes its gradients straight into the bucket, the
         pack copy (598 MB per step at ViT-B/16 + text tower) disappears, ``.grad`` are views of the bucket from the start.
         ``wire_dtype=torch.bfloat16``: the collective runs on a bf16 copy of the bucket (half the bytes over xGMI) and the
-        result is widened back into the fp32 bucket; default None = fp32 on the wire, Horovod's arithmetic."""
+        result is widened back into the fp32 bucket; default None = fp32 on the wire, Horovod's arithmetic.
+        ``segments``: lists of parameters whose gradients are produced on ONE stream each (``tower_segments(model)``: the video
+        tower on the caller's stream, the text tower on its side stream); a bucket never spans two segments, so a bucket is packed
+        and handed to the collective on the stream that produced it and no stream ever waits for another one inside backward."""
         self.group = group
         self.average = average
         self.wire_dtype = wire_dtype
@@ -167,14 +179,20 @@ class GradBucketReducer:
             for q in unit:
                 seen.add(id(q))
             units.append(unit)
-        cur, cur_n = [], 0
+        seg_of = {}
+        for i, seg in enumerate(segments or ()):
+            for p in seg:
+                seg_of.setdefault(id(p), i)
+        cur, cur_n, cur_seg = [], 0, None
         for unit in units:
             n = sum(p.numel() for p in unit)
-            if cur and cur_n + n > cap:
+            useg = seg_of.get(id(unit[0]), -1)
+            if cur and (cur_n + n > cap or useg != cur_seg):
                 self._make_bucket(cur)
                 cur, cur_n = [], 0
             cur.extend(unit)
             cur_n += n
+            cur_seg = useg
         if cur:
             self._make_bucket(cur)
         self._sinks = []
@@ -193,7 +211,23 @@ class GradBucketReducer:
                 key = XF.grad_sink_key(gparams)
                 XF.GRAD_SINKS[key] = b["flat"][off:off + n]
                 self._sinks.append(key)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self._active else []
+        # One hook per layout group, not per parameter: the 16 gradients of an encoder layer leave ONE autograd node together and their
+        # AccumulateGrad nodes (top priority in the engine's ready queue) all run before any other node does, so the hook of the
+        # group's first parameter stands for the group -- credited when the NEXT hook of any kind fires (by then the other 15 have
+        # been accumulated; the hook itself may fire in the middle of its own group) or in synchronize().  ~45 Python hook calls per
+        # step instead of ~400: with per-parameter hooks and events the backward of a data-parallel step was HOST-bound
+        # (profiles/r04w_forced_collectives_timeline.txt: +7.6 ms of enqueue time per step).
+        self._group_rep, grouped = {}, set()
+        if self._active:
+            for gparams in layout_groups or ():
+                gparams = [p for p in gparams if p.requires_grad]
+                if not gparams or id(gparams[0]) not in group_of or id(gparams[0]) in self._group_rep:
+                    continue
+                self._group_rep[id(gparams[0])] = (self._bucket_of[id(gparams[0])], tuple(gparams))
+                grouped.update(id(q) for q in gparams[1:])
+        self._pending = None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_group if id(p) in self._group_rep else self._on_grad)
+                       for p in self.params if id(p) not in grouped] if self._active else []
         self._sync = True
         backend = dist.get_backend(group) if self._active else ""
         self._avg_in_collective = average and backend == "nccl"      # RCCL divides inside the reduction; gloo has no AVG
@@ -212,9 +246,9 @@ class GradBucketReducer:
         return ctx()
 
     def _make_bucket(self, ps):
-        # `events`: one CUDA event per parameter, recorded on the stream its gradient was produced on (the text tower runs
-        # on a side stream): the stream that packs the bucket waits for all of them first
-        b = dict(flat=None, params=list(ps), views=None, ready=0, work=None, n=sum(p.numel() for p in ps), events={})
+        # `marks`: (stream, event) per hook of this step -- the event is recorded on the stream autograd produced those gradients on
+        # (the text tower runs on a side stream), when the hook fires; `pool`: the events, reused step after step
+        b = dict(flat=None, params=list(ps), views=None, ready=0, work=None, n=sum(p.numel() for p in ps), marks=[], pool=[])
         for p in ps:
             self._bucket_of[id(p)] = b
         self.buckets.append(b)
@@ -229,12 +263,25 @@ class GradBucketReducer:
             b["flat"], b["views"] = flat, views
 
     def _launch(self, b):
-        """pack the bucket (one multi-tensor copy; parameters without a gradient contribute zeros) and all-reduce."""
+        """pack the bucket (one multi-tensor copy; parameters without a gradient contribute zeros) and all-reduce -- on the stream
+        that produced the bucket's gradients, whichever hook happens to complete the bucket (the group hooks credit a layer one hook
+        late, possibly from another tower's hook): a bucket of one stream waits for nothing; a mixed bucket runs on the stream of its
+        last gradient and waits for the hook-time events of the others."""
         self._ensure_flat(b)
-        if b["events"]:
-            cur = torch.cuda.current_stream(b["flat"].device)
-            for ev in b["events"].values():
-                cur.wait_event(ev)
+        marks = b["marks"]
+        if marks:
+            target = marks[-1][0]
+            with torch.cuda.stream(target):
+                foreign = False
+                for st, ev in marks:
+                    if st.cuda_stream != target.cuda_stream:
+                        target.wait_event(ev)
+                        foreign = True
+                self._pack_and_reduce(b, foreign, target)
+        else:
+            self._pack_and_reduce(b, False, None)
+
+    def _pack_and_reduce(self, b, foreign, cur):
         src, dst = [], []
         for p, v in zip(b["params"], b["views"]):
             if p.grad is None:
@@ -244,7 +291,7 @@ class GradBucketReducer:
                 dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
-            if b["events"]:
+            if foreign:
                 # the sources may have been produced (and allocated) on another stream: re-pointing .grad below drops
                 # their last reference, and the caching allocator would hand the block back to the PRODUCER stream's pool
                 # at once -- where ongoing backward work could overwrite it while this copy is still queued
@@ -253,6 +300,9 @@ class GradBucketReducer:
                         p.grad.record_stream(cur)      # the ORIGINAL gradient (a .float() temporary is already cur's)
         for p, v in zip(b["params"], b["views"]):
             p.grad = v
+        if _DEBUG_NO_COMM:          # probe (tools): everything but the collective itself
+            b["work"] = _NoWork()
+            return
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
         if self.wire_dtype is not None and self.wire_dtype != torch.float32:
             if b.get("wire") is None:
@@ -262,34 +312,67 @@ class GradBucketReducer:
         else:
             b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
-    def _on_grad(self, p):
-        if not self._sync:
-            return
+    def _mark(self, p):
+        """(stream, event recorded now) for a CUDA gradient: every kernel that produced the hook's gradients has been issued"""
+        if not p.is_cuda:
+            return None
+        st = torch.cuda.current_stream(p.device)
         b = self._bucket_of[id(p)]
-        if b["work"] is not None or b["ready"] >= len(b["params"]):
+        i = len(b["marks"]) + (1 if self._pending is not None and self._pending[0] is b else 0)
+        while len(b["pool"]) <= i:
+            b["pool"].append(torch.cuda.Event())
+        ev = b["pool"][i]
+        ev.record(st)
+        return st, ev
+
+    def _credit(self, b, n, mark):
+        if b["work"] is not None or b["ready"] + n > len(b["params"]):
             raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket whose all-reduce is already in flight -- "
                                "run all but the last micro-step of a gradient-accumulation step under reducer.no_sync(), "
                                "and call synchronize() + zero_grad() between optimizer steps")
-        if p.is_cuda:                      # the hook runs on the stream autograd produced this gradient on
-            ev = b["events"].get(id(p))
-            if ev is None:
-                ev = b["events"][id(p)] = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(p.device))
-        b["ready"] += 1
-        if b["ready"] == len(b["params"]) and b["work"] is None:
+        if mark is not None:
+            b["marks"].append(mark)
+        b["ready"] += n
+        if b["ready"] == len(b["params"]):
             self._launch(b)
+
+    def _flush_pending(self):
+        if self._pending is not None:
+            (b, gparams, mark), self._pending = self._pending, None
+            if any(q.grad is None for q in gparams):
+                raise RuntimeError("GradBucketReducer: a layout group's gradients did not arrive together (the group hook assumes one "
+                                   "autograd node produces all of them, as functional.EncoderLayerFn does)")
+            self._credit(b, len(gparams), mark)
+
+    def _on_group(self, p):
+        """hook of a layout group's first parameter: the group is credited at the next hook / in synchronize()"""
+        if not self._sync:
+            return
+        self._flush_pending()
+        b, gparams = self._group_rep[id(p)]
+        self._pending = (b, gparams, self._mark(p))
+
+    def _on_grad(self, p):
+        if not self._sync:
+            return
+        self._flush_pending()
+        self._credit(self._bucket_of[id(p)], 1, self._mark(p))     # the hook runs on the stream autograd produced this gradient on
 
     def synchronize(self):
         """Wait for every bucket (launching those whose parameters did not all receive a gradient) and average."""
         if not self._active:
             return
         W = world_size()
+        if self._sync:
+            self._flush_pending()
+        self._pending = None
         for b in self.buckets:
             if b["work"] is None:
                 self._launch(b)
         for b in self.buckets:
             b["work"].wait()
             b["work"] = None
+            b["marks"].clear()
             if b.get("wire") is not None:
                 b["flat"].copy_(b["wire"])
             if self.average and not self._avg_in_collective:
@@ -301,8 +384,10 @@ class GradBucketReducer:
         adopted without an accumulate kernel."""
         for p in self.params:
             p.grad = None
+        self._pending = None
         for b in self.buckets:
             b["ready"] = 0
+            b["marks"].clear()
         if self._sinks:
             from . import functional as XF
             XF.release_grad_sinks()
@@ -316,6 +401,23 @@ class GradBucketReducer:
                 XF.GRAD_SINKS.pop(key, None)
             self._sinks = []
             XF.release_grad_sinks()
+
+
+def tower_segments(model: torch.nn.Module):
+    """For ``GradBucketReducer(segments=...)``: [video tower + its projection, text tower + its projection] of a ``VidCLIP`` /
+    ``CLIPModel`` -- the two parameter sets whose gradients ``CLIPModel.forward`` produces on two different streams (the text tower
+    runs on a side stream, modeling/CLIP_ViP.py).  Parameters outside both (logit_scale) form buckets of their own."""
+    clip = getattr(model, "clipmodel", model)
+    segs = []
+    for tower, proj in (("vision_model", "visual_projection"), ("text_model", "text_projection")):
+        ps = []
+        for name in (tower, proj):
+            m = getattr(clip, name, None)
+            if m is not None:
+                ps.extend(m.parameters())
+        if ps:
+            segs.append(ps)
+    return segs
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):

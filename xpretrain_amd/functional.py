@@ -252,7 +252,31 @@ def _native_ok(x, vecs, mats, pad_mask) -> bool:
 # XPRETRAIN_FWD_SPLIT=0: the whole batch as one chain (A/B switch for the two half-batch chains of the video tower's forward)
 FWD_SPLIT = os.environ.get("XPRETRAIN_FWD_SPLIT", "1") != "0"
 FWD_SPLIT_MIN_ROWS = 8192          # below this a half-batch launch no longer fills the chip beside its twin
+# XPRETRAIN_FWD_SPLIT_STREAM: which stream the second chain runs on.  "side" (default): the library's weight-gradient stream, idle
+# during the forward (xp_side_stream) -- the step then touches main + text tower + side = three streams, as before the split.  "own":
+# a torch stream of its own.  Same speed on one GPU (15.75 vs 15.75-15.79 ms per step, profiles/r04w_in_step_ab_second_chain_stream.txt);
+# the fewer streams a step touches the better it survives the streams a collective library or a prefetcher adds: a fifth stream
+# touched by the step cost 5 ms per step on this runtime, a fourth nothing (profiles/r04u_stream_count_probe.txt).
+FWD_SPLIT_STREAM = os.environ.get("XPRETRAIN_FWD_SPLIT_STREAM", "side")
 _SPLIT_STREAMS = {}
+
+
+def second_chain_stream_mode() -> str:
+    return "own" if FWD_SPLIT_STREAM == "own" else "side"
+
+
+def _second_chain_stream(device):
+    st = _SPLIT_STREAMS.get(device.index)
+    if st is None:
+        if second_chain_stream_mode() == "side":
+            with torch.cuda.device(device):
+                ptr = L.lib().xp_side_stream()
+            if ptr:
+                st = torch.cuda.ExternalStream(ptr, device=device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+        _SPLIT_STREAMS[device.index] = st
+    return st
 
 
 class ForwardSplit:
@@ -261,15 +285,12 @@ class ForwardSplit:
     second stream into the second half of the SAME full-batch buffers.  The chains never wait for each other between layers: one
     chain's HBM-bound kernels (LayerNorm, attention, GEMM epilogues) run beside the other's MFMA main loops, and each chain's 111- /
     333- / 444-tile GEMMs fill the CUs the other leaves idle.  The backward sees ordinary full-batch buffers.  Results are bit-identical
-    to the single chain (the same kernels compute every row).  Forward-only passes free a layer's buffers while the second chain may
-    still be reading them: those are handed to the caching allocator with ``record_stream`` (reuse waits for the chain).
-    Measured: profiles/r04r_split_batch_probe_gemm256_forced.txt (probe), r04s_ab_fwd_split.txt (the step: -0.45 ms)."""
+    to the single chain (the same kernels compute every row).  Only while activations are kept (training passes): nothing of a layer is
+    freed before the chains are joined.  Measured: profiles/r04r_split_batch_probe_gemm256_forced.txt (probe),
+    r04s_in_step_ab_forward_two_chains.txt (the step: -0.46 ms)."""
 
     def __init__(self, device):
-        st = _SPLIT_STREAMS.get(device.index)
-        if st is None:
-            st = _SPLIT_STREAMS[device.index] = torch.cuda.Stream(device=device)
-        self.stream = st
+        self.stream = _second_chain_stream(device)
         self.main = torch.cuda.current_stream(device)
         self.stream.wait_stream(self.main)          # fork: everything the tower's input depends on
 
@@ -320,10 +341,6 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
                 if side_x2 is not None:
                     a.side_x2 = side_x2.data_ptr() + so
             L.check(L.lib().xp_encoder_layer_fwd(C.byref(a), H._stream()), "xp_encoder_layer_fwd")
-    if split is not None and not keep_pre:      # forward-only pass: these die before the chains are joined
-        for t in (x, arena, x3, side, side_out):
-            if t is not None:
-                t.record_stream(split.stream)
     return x3, arena, side_out, side_x2
 
 
@@ -448,7 +465,7 @@ class EncoderLayerFn(torch.autograd.Function):
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
         if LAYER_CALLS and _native_ok(x, (ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2), (Wqkv, Wo, W1, W2), pad_mask):
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
-            if split is not None and (size is None or B % 2 or pad_mask is not None):
+            if split is not None and (not training or size is None or B % 2 or pad_mask is not None):
                 split = None
             if split is not None and WEIGHTS.casts != casts0:       # a weight copy was (re)made on this stream just now: the second
                 split.stream.wait_stream(torch.cuda.current_stream())   # chain must not read it before the cast has run
