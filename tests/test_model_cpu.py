@@ -98,3 +98,31 @@ def test_output_objects_resolve_lazy_fields_everywhere():
     assert out.to_tuple()[1] is out.pooler_output and len(out.to_tuple()) == 2
     with pytest.raises(AttributeError):
         out.no_such_field
+
+
+def test_tower_segments_and_layer_groups_partition_the_parameters():
+    """distributed.tower_segments / functional.layer_grad_groups on the real module tree: the two towers (each with its projection) are
+    disjoint, together they hold every parameter but logit_scale, every encoder layer is one 16-parameter group inside ONE segment --
+    so a GradBucketReducer built from them never mixes gradients of two streams in a bucket and hooks one parameter per layer."""
+    import xpretrain_amd.functional as XF
+    from xpretrain_amd import distributed as D
+    from xpretrain_amd.modeling import VidCLIP
+    m = VidCLIP(_Args(O.hf_config_dict(128, 2, 2, 256, 16, 32, 128, 2, 3, 256, 120, 16, 64), temporal_size=2))
+    segs = D.tower_segments(m)
+    assert len(segs) == 2
+    ids = [set(map(id, s)) for s in segs]
+    assert not (ids[0] & ids[1])
+    rest = [n for n, p in m.named_parameters() if id(p) not in ids[0] | ids[1]]
+    assert rest == ["clipmodel.logit_scale"], rest
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert all(names[i].startswith(("clipmodel.vision_model.", "clipmodel.visual_projection.")) for i in ids[0])
+    assert all(names[i].startswith(("clipmodel.text_model.", "clipmodel.text_projection.")) for i in ids[1])
+    groups = XF.layer_grad_groups(m)
+    assert len(groups) == 2 + 3 and all(len(g) == 16 for g in groups)
+    for g in groups:
+        assert len({0 if id(p) in ids[0] else 1 for p in g}) == 1
+    # single process: the reducer is inert, but its bucket plan is built all the same
+    red = D.GradBucketReducer(m.parameters(), bucket_mb=0.5, layout_groups=groups, segments=segs)
+    for b in red.buckets:
+        assert len({(id(p) in ids[0], id(p) in ids[1]) for p in b["params"]}) == 1
+    assert XF.second_chain_stream_mode() in ("side", "own")
