@@ -236,10 +236,12 @@ class CLIPEncoder(nn.Module):
         ``collect`` / ``collect_side``: lists that receive every layer output (compute dtype, as ``last_hidden_state``) and its
         fp32 side rows (``output_hidden_states``)."""
         ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
-        # video tower, training pass: two half-batch chains on two streams (functional.ForwardSplit), joined after the last layer
+        # video tower, training pass: two half-batch chains on two streams (functional.ForwardSplit), joined after the last layer.
+        # x.requires_grad: every layer then builds its autograd node and keeps its buffers until backward -- a layer without a node
+        # (everything frozen under grad mode) would free them while the second chain is still using them.
         split = None
         if (XF.FWD_SPLIT and XF.LAYER_CALLS and inputs_size is not None and pad_mask is None and not ckpt and torch.is_grad_enabled()
-                and x.is_cuda and B % 2 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS):
+                and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS):
             split = XF.ForwardSplit(x.device)
         for layer in self.layers:
             if ckpt:
