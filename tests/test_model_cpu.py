@@ -126,3 +126,20 @@ def test_tower_segments_and_layer_groups_partition_the_parameters():
     for b in red.buckets:
         assert len({(id(p) in ids[0], id(p) in ids[1]) for p in b["params"]}) == 1
     assert XF.second_chain_stream_mode() in ("side", "own")
+
+
+def test_forward_hooks_on_encoder_layers_are_detected():
+    """CLIPEncoder keeps the video tower on ONE chain while any encoder layer carries a forward hook (the hook would read the layer's
+    output on the caller's stream before the second chain has written its half)."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.modeling.CLIP_ViP import _has_forward_hooks
+    m = VidCLIP(_Args(O.hf_config_dict(128, 2, 2, 256, 16, 32, 128, 2, 1, 256, 120, 16, 64), temporal_size=2))
+    layers = m.clipmodel.vision_model.encoder.layers
+    assert not _has_forward_hooks(layers)
+    h = layers[1].register_forward_hook(lambda mod, inp, out: None)
+    assert _has_forward_hooks(layers)
+    h.remove()
+    h = layers[0].register_forward_pre_hook(lambda mod, inp: None)
+    assert _has_forward_hooks(layers)
+    h.remove()
+    assert not _has_forward_hooks(layers)

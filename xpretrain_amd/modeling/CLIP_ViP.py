@@ -222,6 +222,13 @@ class CLIPEncoderLayer(nn.Module):
         return XF.encoder_layer(hidden_states, self, B, S, self.num_heads, inputs_size, pad_mask, side, split)
 
 
+def _has_forward_hooks(layers) -> bool:
+    import torch.nn.modules.module as M
+    if M._global_forward_hooks or M._global_forward_pre_hooks:
+        return True
+    return any(l._forward_hooks or l._forward_pre_hooks for l in layers)
+
+
 class CLIPEncoder(nn.Module):
     """reference: CLIP_ViP.py:614-712"""
 
@@ -241,7 +248,8 @@ class CLIPEncoder(nn.Module):
         # (everything frozen under grad mode) would free them while the second chain is still using them.
         split = None
         if (XF.FWD_SPLIT and XF.LAYER_CALLS and inputs_size is not None and pad_mask is None and not ckpt and torch.is_grad_enabled()
-                and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS):
+                and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS
+                and not _has_forward_hooks(self.layers)):     # (a hook would read a layer's output before the second chain wrote it)
             split = XF.ForwardSplit(x.device)
         for layer in self.layers:
             if ckpt:
