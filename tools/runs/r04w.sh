@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical run script: XPRETRAIN_WGRAD_PRIORITY and XPRETRAIN_FWD_CHAINS were experiment switches of that moment -- the weight-gradient stream now has
+# the default priority and there are exactly two forward chains; the tree no longer reads them)
 R=${GRAFT_REPO_ROOT:-.}
 cd $R; O=$R/gpurun_out/r04w; mkdir -p $O
 export TMPDIR=/tmp
