@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmarks of the individual HIP kernels at BASELINE cfg #2 shapes (B=8, T=12, 224^2, ViT-B/16).
-Run on the GPU box:  python tools/bench_kernels.py [gemm|ln|attn|all]  -> prints one line per kernel."""
+Run on the GPU box:  python tools/bench_kernels.py [gemm|gemmfwd|ln|attn|all]  -> prints one line per kernel."""
 import sys
 
 import torch
@@ -10,7 +10,7 @@ from xpretrain_amd import hip_ops as H  # noqa: E402
 from xpretrain_amd import _lib as L  # noqa: E402
 
 
-def timeit(fn, iters=20, warmup=3):
+def timeit(fn, iters=200, warmup=300):     # (sustained clocks: a cold GPU ramps for the first few hundred launches, tools/power_probe.py)
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -23,7 +23,7 @@ def timeit(fn, iters=20, warmup=3):
     return st.elapsed_time(en) / iters * 1e3   # us
 
 
-def bench_gemm():
+def bench_gemm(fwd_only=False):
     M = 8 * 2356
     bf = torch.bfloat16
     for name, N, K, kw in [("qkv", 2304, 768, dict(epilogue=L.EPI_BIAS_QSCALE, scale=0.125, scale_cols=768)),
@@ -40,6 +40,8 @@ def bench_gemm():
             kw["aux"] = torch.empty(M, N, dtype=bf, device="cuda")
         us = timeit(lambda: H.gemm(A, W, M, N, K, out=out, bias=bias, **kw))
         print(f"gemm fwd {name:4s} M={M} N={N} K={K}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
+        if fwd_only:
+            continue
         # dX: dY[M,N] . W[N,K]
         dY = torch.randn(M, N, device="cuda").to(bf)
         dX = torch.empty(M, K, dtype=bf, device="cuda")
@@ -87,6 +89,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
         bench_gemm()
+    if what == "gemmfwd":
+        bench_gemm(fwd_only=True)
     if what in ("ln", "all"):
         bench_ln()
     if what in ("attn", "all"):

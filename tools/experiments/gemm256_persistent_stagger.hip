@@ -117,24 +117,80 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int ot, int ks, int lan
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool AKS, bool BKS>
-__global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
+// The kernel's parameter block, re-read from the kernarg segment through a pointer the optimiser cannot see through.  Inside the
+// persistent tile loop every field of the by-value parameter is loop-invariant: hipcc hoists all of them (the epilogue's ~100
+// scalars included) in front of the loop, keeps them in SGPRs across the main loop, and spills -- 97 SGPRs to VGPR lanes, 61 VGPRs
+// to scratch in the first build of the loop.  Two reads per tile (main-loop fields at the top, epilogue fields after the k loop)
+// give the live ranges of the one-tile kernel back.
+__device__ __forceinline__ KParams load_kparams() {
+  const __attribute__((address_space(4))) char* q =
+      (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  // word by word through the CONSTANT address space: scalar loads, wave-uniform values (a generic-pointer memcpy turns the block
+  // into vector loads and every buffer descriptor built from it into a waterfall loop)
+  static_assert(sizeof(KParams) % 4 == 0, "KParams is copied in 32-bit words");
+  constexpr int NW = sizeof(KParams) / 4;
+  const __attribute__((address_space(4))) unsigned* w = (const __attribute__((address_space(4))) unsigned*)q;
+  unsigned buf[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) buf[i] = w[i];
+  KParams P;
+  __builtin_memcpy(&P, buf, sizeof(KParams));
+  return P;
+}
+
+// ABL (timing experiments only, results are wrong): 1 = no DMA inside the loop, 2 = no fragment reads inside the loop, 3 = no MFMAs,
+// 4 = no epilogue (XPRETRAIN_GEMM256_ABL; where the energy of a launch goes -- the chip is power-limited, so time IS energy).
+template <bool AKS, bool BKS, int ABL = 0>
+__global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int nwg = p_arg.tiles_m * p_arg.tiles_n;
+  const int phase_delay = p_arg.phase_delay, flat_split = p_arg.flat_split;
   // Split-K launches (dW: k = the token dimension) with flat_split > 0 use a 1-D grid over (k-chunk, tile) pairs, CHUNK-MAJOR in
   // the XCD-contiguous order: an XCD's ~32 concurrent workgroups are (almost) all the tiles of ONE k-chunk, so its L2 fetches every
   // operand panel of that chunk once.  With the (tile, z) grid each XCD held ~4.5 tiles of EVERY chunk and each of the chunk's
   // panels was fetched by every XCD that touched it: 386 MB from the fabric for 145 MB of operands at dW1 (PMC, profiles/r03y).
+  // Phase stagger (multi-round launches): every tile takes the same time and the hardware dispatcher places workgroups in order, so
+  // the rounds of a one-tile-per-workgroup launch stay in lock step and the epilogues of a round coincide chip-wide -- one HBM write
+  // burst during which no CU issues an MFMA (tools/gemm_timeline.py: 7-8 us of every 27 us round at fc1; a CU freed early gets no
+  // new workgroup until its turn in the dispatcher's order comes).  PERSISTENT launches (grid = the CU count, every workgroup walks
+  // its own tile list) keep whatever phase they are given: the workgroups on odd slots of every XCD start `phase_delay` late, from
+  // then on their epilogues fall into the other half's main loops.
+  const int phase_groups = p_arg.phase_first > 1 ? p_arg.phase_first : 2;       // (power of two)
+  const int phase_id = ((int)blockIdx.x >> 3) & (phase_groups - 1);
+  if (phase_delay > 0 && phase_id > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)phase_delay * phase_id;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+  // Tile list of this workgroup: virtual block ids blockIdx.x + i * gridDim.x (the ids the hardware would have dispatched to this
+  // slot, so the XCD-contiguous remap below is unchanged); the ids of the last, partial round go to the early (even-slot) workgroups
+  // first.  One-tile-per-workgroup launches (gridDim.x == the tile count) make exactly one pass.
+  const int total = flat_split > 0 ? nwg * flat_split : nwg;
+  const int G = (int)gridDim.x, full_rounds = total / G, extras = total - full_rounds * G;
+  for (int it = 0; it <= full_rounds; ++it) {
+  const KParams p = load_kparams();                // (fields of the main loop; the epilogue re-reads the block below)
+  unsigned long long* tr = p.dbg;
+  int vb;
+  if (it < full_rounds) vb = (int)blockIdx.x + it * G;
+  else {
+    int idx = (int)blockIdx.x;
+    if (phase_delay > 0 && G % (8 * phase_groups) == 0) {      // earliest phase group first
+      const int slot = (int)blockIdx.x >> 3, a = (slot / phase_groups) * 8 + ((int)blockIdx.x & 7);
+      idx = phase_id * (G / phase_groups) + a;
+    }
+    if (idx >= extras) break;
+    vb = full_rounds * G + idx;
+  }
   int bid, zs, nsplit;
   if (p.flat_split > 0) {
-    const int l = xcd_remap(blockIdx.x, nwg * p.flat_split, 1);
+    const int l = xcd_remap(vb, nwg * p.flat_split, 1);
     zs = l / nwg; bid = l - zs * nwg; nsplit = p.flat_split;
   } else {
-    bid = xcd_remap(blockIdx.x, nwg, p.xcd_remap); zs = blockIdx.z; nsplit = gridDim.z;
+    bid = xcd_remap(vb, nwg, p.xcd_remap); zs = blockIdx.z; nsplit = gridDim.z;
   }
   int tm, tn;
   tile_of(bid, p.tiles_m, p.tiles_n, p.group_n, tm, tn);
@@ -156,10 +212,9 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const bool trace = p.dbg != nullptr && bid == nwg / 2 && zs == 0 && wave == 0;
-  unsigned long long* tr = p.dbg;
   if (trace && lane == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[1] = nk; }
   // per-tile timeline (tools/gemm_timeline.py sets tr[4] = 0x7ace and provides 64 + 4 * tiles words): constant-rate 100 MHz stamps
-  // at the start / the end of the main loop / the end of the epilogue (stores acknowledged) from wave 0 of EVERY workgroup
+  // at start / end of the main loop / end of the epilogue + the hardware id, from wave 0 of EVERY workgroup
   const bool tline = p.dbg != nullptr && wave == 0 && lane == 0 && zs == 0 && tr[4] == 0x7aceull;
   if (tline) { tr[64 + bid * 4 + 0] = __builtin_amdgcn_s_memrealtime(); tr[64 + bid * 4 + 3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
 
@@ -186,15 +241,19 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
           _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                            \
-            acc[hb * 2 + nt][(HA) * 4 + mt] = mma16(fb[hb][ks][nt], fa[ks][mt], acc[hb * 2 + nt][(HA) * 4 + mt]); \
+            if constexpr (ABL != 3)                                                                   \
+              acc[hb * 2 + nt][(HA) * 4 + mt] = mma16(fb[hb][ks][nt], fa[ks][mt], acc[hb * 2 + nt][(HA) * 4 + mt]); \
+            else asm volatile("" ::"v"(fb[hb][ks][nt]), "v"(fa[ks][mt]));                             \
     __builtin_amdgcn_s_setprio(0);                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     __builtin_amdgcn_s_barrier();                                                                     \
   } while (0)
 #define XP_READ_A(TILE)                                                                               \
+  if constexpr (ABL != 2)                                                                             \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) fa[ks][mt] = frag<AKS>(TILE, wm * 4 + mt, ks, lane)
 #define XP_READ_B(DST, TILE)                                                                          \
+  if constexpr (ABL != 2)                                                                             \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) DST[ks][nt] = frag<BKS>(TILE, wn * 2 + nt, ks, lane)
 
@@ -213,7 +272,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     __builtin_amdgcn_sched_barrier(0);
     XP_READ_A(slot(t, 0));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TAIL <= 1) { ga.issue(slot(t + 1, 0), 0, t + 1); gb.issue(slot(t + 1, 1), 1, t + 1); }
+    if constexpr (TAIL <= 1 && ABL != 1) { ga.issue(slot(t + 1, 0), 0, t + 1); gb.issue(slot(t + 1, 1), 1, t + 1); }
     wait_vmcnt<(TAIL <= 1 ? 4 : 0)>();
     XP_PHASE_MMA(0);
     // ---- phase 1: A1 x (B0, B1); issues A1(t+1), B0(t+2); afterwards A0, B1 of k-tile t+1 have landed ----
@@ -221,8 +280,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     __builtin_amdgcn_sched_barrier(0);
     XP_READ_A(slot(t, 2));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TAIL <= 1) ga.issue(slot(t + 1, 2), 1, t + 1);
-    if constexpr (TAIL == 0) gb.issue(slot(t + 1, 3), 0, t + 2);
+    if constexpr (TAIL <= 1 && ABL != 1) ga.issue(slot(t + 1, 2), 1, t + 1);
+    if constexpr (TAIL == 0 && ABL != 1) gb.issue(slot(t + 1, 3), 0, t + 2);
     wait_vmcnt<(TAIL == 0 ? 4 : (TAIL == 1 ? 2 : 0))>();
     XP_PHASE_MMA(1);
   };
@@ -238,6 +297,13 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
   if (tline) tr[64 + bid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 
   // ---- epilogue: wave-private staging, MT/2 rounds of 32 rows x 64 columns fp32 ------------------------------------
+  {
+  const KParams p = load_kparams();                // (the epilogue's fields, read here: see load_kparams)
+  // the epilogue's lane-dependent constants (staging addresses, column offsets) are invariant in the tile loop too: derived from an
+  // opaque copy of the lane id they are recomputed here instead of living in ~40 registers across the main loop
+  int lane_opaque = lane;
+  asm volatile("" : "+v"(lane_opaque));
+  const int lane = lane_opaque;
   constexpr int CW = NT * 16;
   char* stg = smem + wave * (32 * CW * 4);
   const int i16 = lane & 15, g = lane >> 4;
@@ -254,6 +320,14 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
+  if constexpr (ABL == 4) {                           // keep the accumulators alive without the epilogue
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (s == 12345.678f) Cf[0] = s;
+  } else {
   const bool fast = fast_epi_dispatch(p, [&](auto epi_c, auto f32_c, auto cs_c) {
     constexpr int EPI = decltype(epi_c)::value;
     constexpr bool F32 = decltype(f32_c)::value;
@@ -307,13 +381,17 @@ __global__ __launch_bounds__(NTH, 2) void gemm256_kernel(KParams p) {
     }
   });
   (void)fast;          // the launcher admits only (epilogue, output type) pairs the fast path specialises (epi_supported)
+  }
+  }
   if (trace && lane == 0) tr[3] = __builtin_amdgcn_s_memtime();
   if (tline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[64 + bid * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
+  __builtin_amdgcn_s_barrier();                    // (persistent launches) the staging area is ring space of the next tile
+  }   // tile list
 }
 
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, int ABL = 0>
 bool launch_one(const KParams& kp, dim3 grid, hipStream_t st) {
-  auto kern = gemm256_kernel<AKS, BKS>;
+  auto kern = gemm256_kernel<AKS, BKS, ABL>;
   // the 128 KiB dynamic-LDS opt-in is per device: configured once for every device this process launches on
   // (forward thread and autograd thread may both arrive first)
   static std::mutex mu;
@@ -376,14 +454,15 @@ bool xp_gemm256_wanted(const XpGemmDesc* d, int split) {
   return true;
 }
 
-// Tile columns per L2 group (gemm_common.h::tile_of walks column groups, columns fastest inside a group; the XCD-contiguous id
-// ranges then make an XCD own (a row range of) ONE column group).  The weight-side panels an XCD's ~32 resident workgroups sweep in
-// one k pass must stay in its 4 MiB L2 beside the streaming activation panels: with all 12 tile columns of the N = 3072 problems
+// Tile columns per L2 group (gemm_common.h::tile_of walks column groups, rows fastest inside a group's column sweep; the XCD-contiguous
+// id ranges then make an XCD own (a row range of) ONE column group).  The weight-side panels an XCD's ~32 resident workgroups sweep
+// in one k pass must stay in its 4 MiB L2 beside the streaming activation panels: with all 12 tile columns of the N = 3072 problems
 // (4.7 MB of weights) every XCD re-streamed the whole weight matrix once per round -- 194 MB fetched for 34 MB of unique operands
 // (PMC, profiles/r04s_pmc_gemm256.json).  Rule: the fewest column groups (1, 2 or 4 -- they must tile the 8 XCDs) whose weight
 // share is <= 3.6 MB, groups of at least 4 columns (the K = 3072 problems with 3 tile columns lose with a 2 + 1 split: their
-// concurrent tiles move through k together, the live weight window is small): two groups of 6 columns at N = 3072 (2.4 MB resident
-// per XCD, activations fetched twice), one group everywhere else.  XPRETRAIN_GEMM256_COLGROUPS=n forces n groups (A/B).
+// concurrent tiles move through k together, the live weight window is small); two groups of 6 columns at N = 3072 (2.4 MB resident
+// per XCD, activations fetched twice), one group below.
+// XPRETRAIN_GEMM256_COLGROUPS=n forces n groups (A/B).
 int xp_gemm256_group_n(const XpGemmDesc* d, int tiles_n) {
   static const int forced = getenv("XPRETRAIN_GEMM256_COLGROUPS") ? atoi(getenv("XPRETRAIN_GEMM256_COLGROUPS")) : 0;
   int groups = 1;
@@ -412,6 +491,28 @@ bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStre
   static const bool chunk_major = !getenv("XPRETRAIN_DW_CHUNK_MAJOR") || atoi(getenv("XPRETRAIN_DW_CHUNK_MAJOR")) != 0;   // (A/B switch)
   kp.flat_split = (split > 1 && chunk_major) ? split : 0;
   dim3 grid(kp.tiles_m * kp.tiles_n * (kp.flat_split ? split : 1), 1, kp.flat_split ? 1 : split);
+  // XPRETRAIN_GEMM256_PERSIST=1: multi-round launches without split-K run as persistent workgroups (one per CU of the budget) that
+  // walk their tile lists; XPRETRAIN_GEMM256_PHASE_US = start offset of the odd slots in microseconds (see the kernel).
+  {
+    static const int persist = getenv("XPRETRAIN_GEMM256_PERSIST") ? atoi(getenv("XPRETRAIN_GEMM256_PERSIST")) : 0;
+    static const float phase_us = getenv("XPRETRAIN_GEMM256_PHASE_US") ? (float)atof(getenv("XPRETRAIN_GEMM256_PHASE_US")) : 0.f;
+    const int ncu = xp_get_cu_budget() > 0 ? xp_get_cu_budget() : 256;
+    const int ntile = kp.tiles_m * kp.tiles_n;
+    if (persist && split == 1 && ntile > ncu) {
+      grid = dim3(ncu, 1, 1);
+      static const int groups = getenv("XPRETRAIN_GEMM256_PHASE_GROUPS") ? atoi(getenv("XPRETRAIN_GEMM256_PHASE_GROUPS")) : 2;
+      if (phase_us > 0.f) { kp.phase_delay = (int)(phase_us * 100.f); kp.phase_first = groups; }
+    }
+  }
+  static const int abl = getenv("XPRETRAIN_GEMM256_ABL") ? atoi(getenv("XPRETRAIN_GEMM256_ABL")) : 0;
+  if (!d->a_kstrided && !d->b_kstrided && abl) {
+    switch (abl) {
+      case 1: return launch_one<false, false, 1>(kp, grid, st);
+      case 2: return launch_one<false, false, 2>(kp, grid, st);
+      case 3: return launch_one<false, false, 3>(kp, grid, st);
+      default: return launch_one<false, false, 4>(kp, grid, st);
+    }
+  }
   if (!d->a_kstrided && !d->b_kstrided)      return launch_one<false, false>(kp, grid, st);
   else if (!d->a_kstrided && d->b_kstrided)  return launch_one<false, true>(kp, grid, st);
   else if (d->a_kstrided && d->b_kstrided)   return launch_one<true, true>(kp, grid, st);

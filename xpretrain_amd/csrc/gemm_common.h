@@ -299,6 +299,7 @@ __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int gr
 
 // launcher of the 256x256 family (gemm256.hip); returns false if the problem does not fit its preconditions
 bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStream_t st);
+int xp_gemm256_group_n(const XpGemmDesc* d, int tiles_n);
 bool xp_gemm256_legal(const XpGemmDesc* d);
 bool xp_gemm256_wanted(const XpGemmDesc* d, int split);
 int64_t xp_gemm256_colsum_rows(const XpGemmDesc* d);
