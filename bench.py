@@ -71,6 +71,13 @@ def parse():
     ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step in a HIP graph and replay it "
                     "(works; measured 23.3 vs 23.1 ms/step eager on MI355X -- the step is GPU-bound and replaying a "
                     "600-node multi-stream graph costs the host as much as the eager launches); 0 (default): eager")
+    ap.add_argument("--prefetch", type=int, default=0, help="0 (default, the contract's line): the batch is resident in HBM; 1: every step "
+                    "takes its batch from xpretrain_amd.utils.prefetch.PrefetchLoader over pinned host tensors, copied on the loader's OWN stream "
+                    "while the previous step computes (the reference loop's stream environment, dataloader.py:95-157); 2: the same on the "
+                    "text tower's stream, behind the tower's forward (no additional stream); 3: stream='auto' (2 when data-parallel, else 1).  "
+                    "The line then carries `prefetch` and is NOT the contract's value.")
+    ap.add_argument("--prefetch-dtype", default="fp32", choices=["fp32", "uint8"], help="host frames: normalised fp32 (57.8 MB per step at "
+                    "cfg #2) or decoded uint8 (14.5 MB; normalisation inside the patch-GEMM loader)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, join the process group, print the world size "
                     "measured by a collective and exit (no GPU work; backend gloo when there is no GPU) -- the launcher self-test")
@@ -78,12 +85,7 @@ def parse():
     return ap.parse_args()
 
 
-class Args:
-    def __init__(self, cfg):
-        self.clip_config = cfg
-        self.clip_weights = ""
-        self.clip_vision_additional_config = dict(type="ViP", temporal_size=12, if_use_temporal_embed=1,
-                                                  logit_scale_init_value=4.6, add_cls_num=3)
+from xpretrain_amd.workload import ModelArgs as Args  # noqa: E402  (the args object VidCLIP's constructor reads)
 
 
 def _time(f, iters):
@@ -296,7 +298,7 @@ def main():
         D.FORCE_COLLECTIVES = True
     cu_budget = D.reserve_cus_for_collectives()          # 256 in a 1-rank run
 
-    from oracle import clipvip_oracle as O          # input generator + FLOP model only (not on the timed path)
+    from xpretrain_amd import workload as O         # model dimensions, synthetic inputs, FLOP model
     from xpretrain_amd.modeling import VidCLIP
     from xpretrain_amd.optimization import NCELearnableTempLoss
 
@@ -316,6 +318,8 @@ def main():
     if forced and fmode == "gather":        # the gradient reducer stays out of it
         reducer.remove(); reducer._active = False
     use_graph = a.graph == 1
+    if use_graph and a.prefetch:
+        raise SystemExit("bench.py: --prefetch needs the eager step (a captured graph replays fixed input addresses)")
     # pretrain_vip_base_16.json:68-80: adamw, betas (0.9, 0.98), lr 5e-6, wd 0.05, lr_mul 1, cosine decay with 1 % warmup,
     # grad_norm 5.0; grouping = optimization/utils.py:124-154
     from xpretrain_amd.optimization import AdamW, get_lr_sched, build_e2e_optimizer_w_lr_mul
@@ -324,11 +328,32 @@ def main():
     opt = AdamW([g for g in groups if g["params"]], lr=LR, betas=(0.9, 0.98))
     sched_step = [1000]      # start past the warmup so the synthetic loss moves
     video, ids, mask = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank)
+    batches = None
+    if a.prefetch:
+        # the reference loop's hand-over: a small pool of pinned host batches (a DataLoader with pin_memory=True would produce these),
+        # walked for ever; PrefetchLoader copies batch i+1 while step i runs
+        from xpretrain_amd.utils.prefetch import PrefetchLoader
+        pool = []
+        for i in range(2):
+            v, i_, m_ = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank + 100 * i)
+            if a.prefetch_dtype == "uint8":
+                v = (v * 58.0 + 122.0).clamp_(0, 255).to(torch.uint8)
+            pool.append({"video": v.pin_memory(), "text_input_ids": i_.pin_memory(), "text_input_mask": m_.pin_memory()})
+
+        def forever():
+            while True:
+                for b in pool:
+                    yield b
+        batches = iter(PrefetchLoader(forever(), stream={1: None, 2: "text", 3: "auto"}[a.prefetch]))
     video, ids, mask = video.to(dev), ids.to(dev), mask.to(dev)
     logit_scale = model.clipmodel.logit_scale
     params = [p for p in model.parameters()]
 
     def step():
+        nonlocal video, ids, mask
+        if batches is not None:
+            b = next(batches)
+            video, ids, mask = b["video"], b["text_input_ids"], b["text_input_mask"]
         with torch.no_grad():
             logit_scale.clamp_(0, math.log(200.0))                       # run_pretrain.py:335-340
         out = model(video, ids, mask)
@@ -478,6 +503,8 @@ def main():
                        "global_batch": W * a.batch, "parallelism": f"dp{W}", "final_loss": round(final_loss, 4),
                        "gemm_cu_budget": cu_budget, "grad_wire": os.environ.get("XPRETRAIN_GRAD_WIRE", "fp32"),
                        "forced_one_rank_collectives": forced,
+                       "prefetch": ({"loader": "xpretrain_amd.utils.prefetch.PrefetchLoader", "host_frames": a.prefetch_dtype,
+                                     "copy_stream": {1: "own", 2: "text tower's", 3: "auto"}[a.prefetch]} if a.prefetch else None),
                        "video_forward_chains": 2 if two_chains else 1,
                        "second_chain_stream": XF.second_chain_stream_mode() if two_chains else None,
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager"},

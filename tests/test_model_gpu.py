@@ -223,7 +223,18 @@ def test_output_fields_frozen_text_tower_and_stale_weight_guard():
     assert (to.last_hidden_state.float().cpu() - ref_last).abs().max() < 5e-2 * ref_last.abs().max()
     out = model.clipmodel(input_ids=ids, pixel_values=video, attention_mask=mask)
     want = out.text_embeds @ out.image_embeds.t() * model.clipmodel.logit_scale.exp()
-    assert torch.allclose(out.logits_per_text, want) and torch.allclose(out["logits_per_image"], want.T)
+    assert torch.allclose(out.logits_per_text, want, rtol=1e-4, atol=1e-4) and torch.allclose(out["logits_per_image"], want.T, rtol=1e-4, atol=1e-4)
+    # the lazily computed logits are differentiable like the reference's (CLIP_ViP.py:1151-1153), through the package's own kernels
+    import xpretrain_amd.functional as XF
+    te = out.text_embeds.detach().clone().requires_grad_(True)
+    ie = out.image_embeds.detach().clone().requires_grad_(True)
+    ls = model.clipmodel.logit_scale.detach().clone().requires_grad_(True)
+    w = torch.randn(te.shape[0], ie.shape[0], device=te.device)
+    (XF.SimLogitsFn.apply(te, ie, ls) * w).sum().backward()
+    te2, ie2, ls2 = (t.detach().clone().requires_grad_(True) for t in (te, ie, ls))
+    ((te2 @ ie2.t() * ls2.exp()) * w).sum().backward()
+    for a, b in ((te, te2), (ie, ie2), (ls, ls2)):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-4)
     assert out.loss is None
     with pytest.raises(AttributeError):
         out.no_such_field

@@ -73,3 +73,18 @@ def test_built_kernels_pass_the_lints():
         import pytest
         pytest.skip("no generated code in the tree (run __graft_entry__.build())")
     assert sum(check_isa.check_pk(f) for f in files if not f.endswith("probe.s")) == 0
+
+
+def test_workload_module_matches_the_oracle_definitions():
+    """bench.py and the tools build their model / inputs / FLOP count from xpretrain_amd.workload (product side); the oracle keeps its
+    own statement of the same things (test side): same config dict, same tensors from the same seed, same FLOPs"""
+    import torch
+    from oracle import clipvip_oracle as O
+    from xpretrain_amd import workload as Wk
+    for patch, image in ((16, 224), (32, 224), (16, 448)):
+        assert Wk.vit_b_config(patch, image) == O.vit_b_config(patch, image)
+    for args in ((2, 2, 32, 16), (3, 4, 64, 32)):
+        for a, b in zip(Wk.synthetic_inputs(*args, seed=7), O.synthetic_inputs(*args, seed=7)):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+    for args in ((12, 224, 32, 16), (8, 448, 32, 16), (2, 224, 16, 32)):
+        assert Wk.flops_per_pair(*args) == O.flops_per_pair(*args)

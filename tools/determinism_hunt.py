@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-from oracle import clipvip_oracle as O  # noqa: E402  (input generator / config only)
+from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)
 from xpretrain_amd import hip_ops as H  # noqa: E402
 
 

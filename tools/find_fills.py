@@ -8,7 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
-from oracle import clipvip_oracle as O  # noqa: E402
+from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)
 from bench import Args  # noqa: E402
 from xpretrain_amd import distributed as D  # noqa: E402
 from xpretrain_amd.modeling import VidCLIP  # noqa: E402

@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from oracle import clipvip_oracle as O  # noqa: E402
+from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)
 from xpretrain_amd import distributed as D  # noqa: E402
 from xpretrain_amd.modeling import VidCLIP  # noqa: E402
 from xpretrain_amd.optimization import AdamW, NCELearnableTempLoss, build_e2e_optimizer_w_lr_mul, get_lr_sched  # noqa: E402

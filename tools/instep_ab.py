@@ -3,7 +3,8 @@
 
     python tools/instep_ab.py [--rounds 3] [--steps 20] [--out gpurun_out/ab.txt] VARIANT [VARIANT ...]
 
-VARIANT = name[@tree][:ENV=value[,ENV=value...]]   e.g.   default   nofwd3:XPRETRAIN_ATTN_FWD3=0   r2@_ab_r2
+VARIANT = name[@tree][:ENV=value[,ENV=value...]][/--bench-flag=value ...]
+          e.g.   default   nofwd3:XPRETRAIN_ATTN_FWD3=0   r2@_ab_r2   pf:XPRETRAIN_BENCH_FORCE_COLLECTIVES=1/--prefetch=1/--prefetch-dtype=uint8
           (tree: another checkout of this repository with its library built, relative to the repository root; default: this one)
 
 Every round runs `python bench.py --no-cpu-baseline --steps N` once per variant, in the order given; the table lists pairs/s,
@@ -20,14 +21,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def parse_variant(text):
+    text, *flags = text.split("/")
     name, _, env = text.partition(":")
     name, _, tree = name.partition("@")
     envs = dict(kv.split("=", 1) for kv in env.split(",") if kv)
-    return name, os.path.join(ROOT, tree) if tree else ROOT, envs
+    return name, os.path.join(ROOT, tree) if tree else ROOT, envs, flags
 
 
-def run(tree, envs, steps):
-    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--steps", str(steps)], cwd=tree, env=dict(os.environ, **envs),
+def run(tree, envs, steps, flags=()):
+    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--steps", str(steps), *flags], cwd=tree, env=dict(os.environ, **envs),
                          capture_output=True, text=True, timeout=900)
     line = next((l for l in out.stdout.splitlines() if l.startswith("{")), None)
     if line is None:
@@ -43,14 +45,14 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     variants = [parse_variant(v) for v in a.variants]
-    res = {name: [] for name, _, _ in variants}
+    res = {name: [] for name, _, _, _ in variants}
     for _ in range(a.rounds):
-        for name, tree, envs in variants:
-            res[name].append(run(tree, envs, a.steps))
+        for name, tree, envs, flags in variants:
+            res[name].append(run(tree, envs, a.steps, flags))
     keys = ("value", "ms_per_step", "vit_forward_ms", "vit_forward_train_mode_ms")
     lines = [f"bench.py --steps {a.steps} --no-cpu-baseline, one box, {a.rounds} interleaved rounds: pairs/s ms/step vit_fwd_ms vit_fwd_train_mode_ms"]
     w = max(len(v) for v in a.variants)
-    for (name, _, _), text in zip(variants, a.variants):
+    for (name, _, _, _), text in zip(variants, a.variants):
         cells = [" ".join("-" if d.get(k) is None else f"{d[k]:.3f}" for k in keys) for d in res[name]]
         med = statistics.median(d["ms_per_step"] for d in res[name])
         lines.append(f"{text:{w}s}  " + " | ".join(cells) + f"  || median {med:.3f} ms/step")

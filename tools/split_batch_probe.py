@@ -19,7 +19,7 @@ import sys
 sys.path.insert(0, os.getcwd())
 import torch  # noqa: E402
 import bench as B  # noqa: E402
-from oracle import clipvip_oracle as O  # noqa: E402
+from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)
 from xpretrain_amd import distributed as D  # noqa: E402
 from xpretrain_amd.modeling import VidCLIP  # noqa: E402
 from xpretrain_amd.optimization import NCELearnableTempLoss, AdamW, get_lr_sched, build_e2e_optimizer_w_lr_mul  # noqa: E402

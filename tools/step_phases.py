@@ -16,7 +16,7 @@ if mode == "forced_nocomm":
     os.environ["XPRETRAIN_DEBUG_REDUCER"] = "nocomm"
 import torch  # noqa: E402
 import bench as B  # noqa: E402
-from oracle import clipvip_oracle as O  # noqa: E402
+from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)
 from xpretrain_amd import distributed as D, functional as XF  # noqa: E402
 from xpretrain_amd.modeling import VidCLIP  # noqa: E402
 from xpretrain_amd.optimization import NCELearnableTempLoss, AdamW, get_lr_sched, build_e2e_optimizer_w_lr_mul  # noqa: E402

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
 import bench as B
-from oracle import clipvip_oracle as O
+from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)
 from xpretrain_amd import distributed as D
 from xpretrain_amd.modeling import VidCLIP
 from xpretrain_amd.optimization import NCELearnableTempLoss

@@ -1157,7 +1157,7 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
     static std::mutex mu;
     static int configured[64] = {0};                  // per device -- 0: not yet, > 0: CU count, -1: refused
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) use3 = false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) use3 = use4 = false;
     else {
       std::lock_guard<std::mutex> lock(mu);
       if (!configured[dev]) {

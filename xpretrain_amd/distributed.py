@@ -266,7 +266,7 @@ class GradBucketReducer:
         """pack the bucket (one multi-tensor copy; parameters without a gradient contribute zeros) and all-reduce -- on the stream
         that produced the bucket's gradients, whichever hook happens to complete the bucket (the group hooks credit a layer one hook
         late, possibly from another tower's hook): a bucket of one stream waits for nothing; a mixed bucket runs on the stream of its
-        last gradient and waits for the hook-time events of the others."""
+        last gradient and waits for the events of the others (recorded when each was credited: _flush_pending / _on_grad)."""
         self._ensure_flat(b)
         marks = b["marks"]
         if marks:
@@ -312,18 +312,20 @@ class GradBucketReducer:
         else:
             b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
-    def _mark(self, p):
-        """(stream, event recorded now) for a CUDA gradient: every kernel that produced the hook's gradients has been issued"""
-        if not p.is_cuda:
+    def _mark(self, b, st):
+        """(stream, event recorded NOW on it) for a bucket's CUDA gradients: every kernel issued on `st` so far is covered"""
+        if st is None:
             return None
-        st = torch.cuda.current_stream(p.device)
-        b = self._bucket_of[id(p)]
-        i = len(b["marks"]) + (1 if self._pending is not None and self._pending[0] is b else 0)
+        i = len(b["marks"])
         while len(b["pool"]) <= i:
             b["pool"].append(torch.cuda.Event())
         ev = b["pool"][i]
         ev.record(st)
         return st, ev
+
+    @staticmethod
+    def _stream_of(p):
+        return torch.cuda.current_stream(p.device) if p.is_cuda else None
 
     def _credit(self, b, n, mark):
         if b["work"] is not None or b["ready"] + n > len(b["params"]):
@@ -338,11 +340,15 @@ class GradBucketReducer:
 
     def _flush_pending(self):
         if self._pending is not None:
-            (b, gparams, mark), self._pending = self._pending, None
+            (b, gparams, st), self._pending = self._pending, None
             if any(q.grad is None for q in gparams):
                 raise RuntimeError("GradBucketReducer: a layout group's gradients did not arrive together (the group hook assumes one "
                                    "autograd node produces all of them, as functional.EncoderLayerFn does)")
-            self._credit(b, len(gparams), mark)
+            # the group's event is recorded HERE, on the stream its first hook ran on: by now the AccumulateGrad nodes of all its
+            # parameters have run (they outrank every other ready task), so the event also covers the `grad += new` kernels of a
+            # gradient-accumulation step and the clones of non-stealable gradients -- an event recorded in the first hook would not,
+            # and a mixed-stream bucket packed on the other tower's stream could read gradients still being accumulated
+            self._credit(b, len(gparams), self._mark(b, st))
 
     def _on_group(self, p):
         """hook of a layout group's first parameter: the group is credited at the next hook / in synchronize()"""
@@ -350,13 +356,14 @@ class GradBucketReducer:
             return
         self._flush_pending()
         b, gparams = self._group_rep[id(p)]
-        self._pending = (b, gparams, self._mark(p))
+        self._pending = (b, gparams, self._stream_of(p))
 
     def _on_grad(self, p):
         if not self._sync:
             return
         self._flush_pending()
-        self._credit(self._bucket_of[id(p)], 1, self._mark(p))     # the hook runs on the stream autograd produced this gradient on
+        b = self._bucket_of[id(p)]
+        self._credit(b, 1, self._mark(b, self._stream_of(p)))     # the hook runs on the stream autograd produced this gradient on
 
     def synchronize(self):
         """Wait for every bucket (launching those whose parameters did not all receive a gradient) and average."""

@@ -282,8 +282,10 @@ def _second_chain_stream(device):
 class ForwardSplit:
     """The video tower's training forward as TWO half-batch chains: samples are independent in the forward, every kernel of a layer
     is row-parallel (GEMM rows, LayerNorm rows, attention per sample), so the second half of the batch runs the same layer call on a
-    second stream into the second half of the SAME full-batch buffers.  The chains never wait for each other between layers: one
-    chain's HBM-bound kernels (LayerNorm, attention, GEMM epilogues) run beside the other's MFMA main loops, and each chain's 111- /
+    second stream into the second half of the SAME full-batch buffers.  The chains do not wait for each other between layers -- except
+    at a layer whose compute-dtype weight copy was (re)cast inside the call (the first pass after a checkpoint load or an optimizer
+    that does not maintain the shadows; xp_adamw_step writes them itself, so training steps never re-cast): the second chain then waits
+    for that cast.  One chain's HBM-bound kernels (LayerNorm, attention, GEMM epilogues) run beside the other's MFMA main loops, and each chain's 111- /
     333- / 444-tile GEMMs fill the CUs the other leaves idle.  The backward sees ordinary full-batch buffers.  Results are bit-identical
     to the single chain (the same kernels compute every row).  Only while activations are kept (training passes): nothing of a layer is
     freed before the chains are joined.  Measured: profiles/r04r_split_batch_probe_gemm256_forced.txt (probe),
@@ -316,6 +318,8 @@ def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1,
         parts = [(plan, 0, 0, None)]
     else:                       # two half-batch chains: (plan of half the batch, first row, first sample, stream)
         hp = _layer_plan(d.rows // 2, D, Dff, d.B // 2, d.S, d.heads, (d.M, d.N, d.L), x.dtype)
+        if (d.rows // 2) % 4:   # the second chain's statistics / stream pointers are offset by rows/2 elements: keep them 16-byte aligned
+            raise RuntimeError(f"ForwardSplit: (B/2)*S = {d.rows // 2} rows per chain must be a multiple of 4")
         parts = [(hp, 0, 0, None), (hp, d.rows // 2, d.B // 2, split.stream)]
     for pl, r0, b0, stream in parts:
         with (torch.cuda.stream(stream) if stream is not None else _NULLCTX):
@@ -760,6 +764,37 @@ class L2NormFn(torch.autograd.Function):
         y, inv = ctx.saved_tensors
         rows, D = y.shape
         return H.l2norm_bwd(dy.contiguous().float(), y, inv, rows, D, ctx.dtype)
+
+
+def _sim(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a . b^T in fp32 through xp_sim_matrix (csrc/loss.hip) -- the package launches no vendor GEMM"""
+    a, b = a.contiguous().float(), b.contiguous().float()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    L.check(L.lib().xp_sim_matrix(H._p(a), H._p(b), H._p(out), a.shape[0], b.shape[0], a.shape[1], H._stream()), "xp_sim_matrix")
+    return out
+
+
+class SimLogitsFn(torch.autograd.Function):
+    """``logits_per_text = text_embeds @ image_embeds.T * logit_scale.exp()`` (CLIP_ViP.py:1151-1153) of ``CLIPModel.forward``:
+    a [B, B] fp32 product that VidCLIP never reads (modeling/CLIP_ViP.py resolves it on access).  Forward and both input gradients
+    are products of the same small-matrix kernel."""
+
+    @staticmethod
+    def forward(ctx, text, image, log_scale):
+        scale = log_scale.detach().float().exp()
+        logits = _sim(text, image) * scale
+        ctx.save_for_backward(text, image, logits, scale)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        text, image, logits, scale = ctx.saved_tensors
+        g = g.contiguous().float()
+        gs = g * scale
+        dt = _sim(gs, image.float().t()).to(text.dtype) if ctx.needs_input_grad[0] else None         # [n, m] . [m, d]
+        di = _sim(gs.t(), text.float().t()).to(image.dtype) if ctx.needs_input_grad[1] else None     # [m, n] . [n, d]
+        dls = (g * logits).sum().reshape(()) if ctx.needs_input_grad[2] else None                     # d/d log_scale of s * e^ls
+        return dt, di, dls
 
 
 class NCELossFn(torch.autograd.Function):

@@ -248,7 +248,7 @@ class CLIPEncoder(nn.Module):
         # (everything frozen under grad mode) would free them while the second chain is still using them.
         split = None
         if (XF.FWD_SPLIT and XF.LAYER_CALLS and inputs_size is not None and pad_mask is None and not ckpt and torch.is_grad_enabled()
-                and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS
+                and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] % 8 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS
                 and not _has_forward_hooks(self.layers)):     # (a hook would read a layer's output before the second chain wrote it)
             split = XF.ForwardSplit(x.device)
         for layer in self.layers:
@@ -576,6 +576,7 @@ class CLIPModel(CLIPPreTrainedModel):
                                                position_ids=position_ids, output_attentions=output_attentions,
                                                output_hidden_states=output_hidden_states)
                 text_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(text_outputs["pooler_output"], self.text_projection.weight))
+                CLIPModel.run_deferred_text_stream_work()       # (e.g. the loader's copy of the NEXT batch: behind the text tower's forward)
             vision_outputs = self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
                                                output_hidden_states=output_hidden_states)
             image_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(vision_outputs["pooler_output"], self.visual_projection.weight))
@@ -593,17 +594,42 @@ class CLIPModel(CLIPPreTrainedModel):
                             output_hidden_states)
 
     overlap_text_tower = os.environ.get("XPRETRAIN_OVERLAP_TEXT", "1") != "0"     # A/B switch (tools/)
-    _side = None
+    _text_streams = {}          # one per device, shared by every model instance (and by utils.prefetch.PrefetchLoader(stream="text"))
+
+    @staticmethod
+    def shared_text_stream(device):
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        st = CLIPModel._text_streams.get(key)
+        if st is None:
+            st = CLIPModel._text_streams[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+        return st
 
     def _text_stream(self, device):
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+        return CLIPModel.shared_text_stream(device)
+
+    # One-shot callables that want to enqueue work on the text tower's stream where it is idle: right behind the tower's forward (the
+    # stream then has nothing to do until the loss's backward reaches the text features).  utils.prefetch.PrefetchLoader(stream="text")
+    # puts the host->device copy of the next batch there; enqueued at hand-over time instead, the copy would sit in FRONT of the tower.
+    _deferred_text_work = []
+
+    @staticmethod
+    def defer_to_text_stream(fn):
+        CLIPModel._deferred_text_work.append(fn)
+
+    @staticmethod
+    def cancel_deferred_text_stream_work(fn):
+        if fn in CLIPModel._deferred_text_work:
+            CLIPModel._deferred_text_work.remove(fn)
+
+    @staticmethod
+    def run_deferred_text_stream_work():
+        while CLIPModel._deferred_text_work:
+            CLIPModel._deferred_text_work.pop(0)()
 
     def _finish(self, image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict, output_hidden_states):
         # CLIP_ViP.py:1151-1158: tiny [B,B] fp32 product; VidCLIP never reads it, so it is resolved on access
-        logits_per_text = _Lazy(lambda: torch.matmul(text_embeds, image_embeds.t()) * self.logit_scale.exp())
-        logits_per_image = _Lazy(lambda: (torch.matmul(text_embeds, image_embeds.t()) * self.logit_scale.exp()).T)
+        logits_per_text = _Lazy(lambda: XF.SimLogitsFn.apply(text_embeds, image_embeds, self.logit_scale))
+        logits_per_image = _Lazy(lambda: XF.SimLogitsFn.apply(text_embeds, image_embeds, self.logit_scale).T)
         loss = None          # the reference returns None as well unless return_loss (:1160-1162)
         if return_loss:      # clip_loss (:70-73) == NCELearnableTempLoss / 2, through the fused HIP loss kernel
             loss = XF.NCELossFn.apply(image_embeds, text_embeds, self.logit_scale) * 0.5
