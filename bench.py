@@ -261,6 +261,67 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
+def parse_rccl_log(text):
+    """channels / algorithm / protocol from RCCL's NCCL_DEBUG=INFO (INIT,TUNING) lines; the raw lines it matched are kept"""
+    import re
+    out = {"coll_channels": None, "ring_channel_lines": 0, "tuning": [], "raw": []}
+    algos = {0: "Tree", 1: "Ring", 2: "CollnetDirect", 3: "CollnetChain", 4: "NVLS", 5: "NVLSTree"}
+    protos = {0: "LL", 1: "LL128", 2: "Simple"}
+    seen = set()
+    for line in text.splitlines():
+        m = re.search(r"(\d+) coll channels", line)
+        if m:
+            out["coll_channels"] = int(m.group(1)); out["raw"].append(line.strip()[-160:])
+        if re.search(r"NCCL INFO Channel \d+/\d+\s*:", line):
+            out["ring_channel_lines"] += 1
+        m = re.search(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", line)
+        if m:
+            key = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)))
+            if key not in seen and len(out["tuning"]) < 12:
+                seen.add(key)
+                out["tuning"].append({"op": key[0], "bytes": key[1], "algo": algos.get(key[2], key[2]), "proto": protos.get(key[3], key[3])})
+    return out
+
+
+def dp_diagnostics(step, reducer, sync, dev, rank, W, n_seen, cu_budget, steps=3):
+    """Per-rank facts of a data-parallel run, gathered on rank 0: the ranks this rank saw, what RCCL chose, the
+    gradient buckets, and the EXPOSED tail of the gradient exchange -- main-stream time inside reducer.synchronize() (everything the
+    backward did not hide), HIP events, mean of `steps` extra steps after the timed region."""
+    import glob
+    exposed = []
+    real_sync = reducer.synchronize
+
+    def timed_sync():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); real_sync(); e1.record()
+        exposed.append((e0, e1))
+    reducer.synchronize = timed_sync
+    try:
+        for _ in range(steps):
+            step()
+        sync()
+    finally:
+        reducer.synchronize = real_sync
+    tail = [e0.elapsed_time(e1) for e0, e1 in exposed]
+    info = {"rank": rank, "n_ranks_seen": n_seen, "device": str(dev), "gemm_cu_budget": cu_budget,
+            "buckets": len(reducer.buckets), "bucket_mb": [round(b["n"] * 4 / 2 ** 20, 1) for b in reducer.buckets],
+            "exposed_grad_exchange_tail_ms": round(sum(tail) / max(len(tail), 1), 3),
+            "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")}}
+    pat = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", "*").replace("%p", str(os.getpid()))
+    text = ""
+    for f in glob.glob(pat) if pat else []:
+        try:
+            text += open(f, errors="replace").read()
+        except OSError:
+            pass
+    info["rccl"] = parse_rccl_log(text) if text else "no RCCL debug file (NCCL_DEBUG_FILE unset or unreadable)"
+    if W > 1:
+        box = [None] * W
+        torch.distributed.all_gather_object(box, info)
+        return box
+    return [info]
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -274,6 +335,12 @@ def main():
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         os.environ.setdefault("NCCL_ALGO", "Ring")
         os.environ.setdefault("NCCL_PROTO", "Simple")
+    if a.gpus > 1 or os.environ.get("XPRETRAIN_BENCH_FORCE_COLLECTIVES", "") in ("1", "gather", "reducer"):
+        # what RCCL actually chose (channels, algorithm, protocol per message size) goes to a per-process file that dp_diagnostics()
+        # parses after the timed region: the first multi-GPU run then shows whether the defaults above were honoured
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "xp_bench_rccl.%h.%p.log"))
     local_rank = D.init_from_env()
     W, rank = D.world_size(), D.rank()
     if W != a.gpus:
@@ -418,6 +485,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
+    dp_diag = dp_diagnostics(step, reducer, sync, dev, rank, W, n_seen, cu_budget) if (W > 1 or (forced and fmode != "gather")) else None
 
     # the dominant forward kernel timed WHERE IT RUNS: three more training steps with the library's GEMM timer armed for the fc1
     # shape (HIP events on the stream the kernel is launched on, around each of its 12 launches per step)
@@ -430,9 +498,11 @@ def main():
     rows_ = a.batch * (4 + a.frames * (a.res // a.patch) ** 2)
     two_chains = XF.FWD_SPLIT and XF.LAYER_CALLS and a.batch % 2 == 0 and rows_ >= XF.FWD_SPLIT_MIN_ROWS
 
-    def timed_fc1(m_rows):
+    def timed_gemm(M_, N_, K_, epi, aks, bks, split):
+        """median HIP-event duration (ms) of the launches of ONE GEMM shape inside three training steps (xp_debug_gemm_timer brackets
+        every matching xp_gemm call on the stream it is launched on -- the weight-gradient stream for the dW GEMMs)"""
         if rank == 0:
-            L.check(L.lib().xp_debug_gemm_timer_arm(m_rows, 3072, 768, L.EPI_BIAS_GELU, 0, 0, 1, 64), "xp_debug_gemm_timer_arm")
+            L.check(L.lib().xp_debug_gemm_timer_arm(M_, N_, K_, epi, aks, bks, split, 64), "xp_debug_gemm_timer_arm")
         for _ in range(3):
             step()
         sync()
@@ -446,11 +516,14 @@ def main():
     import statistics
     from xpretrain_amd import _lib as L
     if two_chains:
-        fc1_two_chain_ms = timed_fc1(rows_ // 2)
+        fc1_two_chain_ms = timed_gemm(rows_ // 2, 3072, 768, L.EPI_BIAS_GELU, 0, 0, 1)
+    # the dominant backward kernel where it runs: dW1 = dpre^T . h2 on the weight-gradient stream, beside the dX chain
+    dw1_split = XF._split_for(3072, 768, rows_, torch.bfloat16, (0, 0, 0))
+    dw1_in_step_ms = timed_gemm(3072, 768, rows_, L.EPI_NONE, 1, 1, dw1_split)
     saved = XF.FWD_SPLIT
     XF.FWD_SPLIT = False
     try:
-        fc1_in_step_ms = timed_fc1(rows_)
+        fc1_in_step_ms = timed_gemm(rows_, 3072, 768, L.EPI_BIAS_GELU, 0, 0, 1)
     finally:
         XF.FWD_SPLIT = saved
 
@@ -489,6 +562,8 @@ def main():
         # back-to-back identical GEMMs run at a lower clock than the same kernel between the step's memory-bound neighbours)
         k_ms = fc1_in_step_ms if fc1_in_step_ms else k_ms_iso
         k_tf = 2.0 * rows * 768 * 3072 / (k_ms * 1e-3) / 1e12
+        bw_ms = dw1_in_step_ms if dw1_in_step_ms else b_ms
+        bw_tf = 2.0 * rows * 768 * 3072 / (bw_ms * 1e-3) / 1e12
         full = rows == 18848
         tr_f, note_f = pmc_traffic("NT_fc1_fwd") if full else (None, "PMC summary exists for the cfg #2 shape only")
         tr_b, note_b = pmc_traffic("SS_dw1") if full else (None, "PMC summary exists for the cfg #2 shape only")
@@ -525,19 +600,28 @@ def main():
                          "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(k_ms, 4),
                          "kernel_ms_source": ("median of the kernel's launches inside 3 training steps after the timed region, run as ONE forward chain "
                                               "(HIP events on the launch stream, xp_debug_gemm_timer)" if fc1_in_step_ms else "30 isolated launches (HIP events)"),
+                         # NOT the shipped configuration: the timed step runs the video tower as two half-batch chains, whose launches share the
+                         # chip (next field); one full-batch launch per layer is the per-kernel quantity a roofline is defined on
+                         "measured_in": "one-chain steps (XPRETRAIN_FWD_SPLIT=0)" if fc1_in_step_ms else "isolated launches",
+                         "rocprof_check": "profiles/r05z_kernel_by_grid.txt: gemm256_kernel<false, false>, 888 workgroups (tools/kernel_by_grid.py)",
                          # the shipped step: two half-batch chains; a [rows/2] launch beside the other chain's kernels (a shared-chip duration)
                          "kernel_ms_half_batch_launch_beside_the_other_chain": None if fc1_two_chain_ms is None else round(fc1_two_chain_ms, 4),
                          "kernel_ms_isolated": round(k_ms_iso, 4), "frac_isolated": round(k_tf_iso / PEAK_BF16_TFLOPS, 4),
                          "traffic": tr_f, "traffic_unit": "bytes/launch", "traffic_source": note_f,
                          "algorithmic_bytes": (rows * 768 + 3072 * 768 + 2 * rows * 3072) * 2},
             # dominant backward kernel (incl. its split-K reduce); algorithmic bytes = dpre + h2 + fp32 dW
-            "roofline_bwd": {"bound": "mfma", "kernel": f"gemm256_kernel<SS> dW1 = dpre^T.h2 [3072x{rows}]x[{rows}x768] split-K + reduce",
-                             "achieved": round(b_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(b_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(b_ms, 4),
-                             "kernel_ms_source": "30 isolated launches incl. the reduce (in the step this GEMM runs on the weight-gradient stream beside the dX chain: its in-step duration is an overlapped one)",
+            "roofline_bwd": {"bound": "mfma", "kernel": f"gemm256_kernel<SS> dW1 = dpre^T.h2 [3072x{rows}]x[{rows}x768] split-K {dw1_split} into fp32 slabs",
+                             "achieved": round(bw_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(bw_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(bw_ms, 4),
+                             "kernel_ms_source": ("in-step: median of the GEMM kernel's launches inside 3 training steps (HIP events on the weight-gradient "
+                                                  "stream it is launched on, xp_debug_gemm_timer); it runs beside the dX chain of the main stream, so the "
+                                                  "duration is a shared-chip one" if dw1_in_step_ms else "30 isolated launches incl. the reduce"),
+                             "kernel_ms_isolated_with_reduce": round(b_ms, 4), "frac_isolated_with_reduce": round(b_tf / PEAK_BF16_TFLOPS, 4),
                              "traffic": tr_b, "traffic_unit": "bytes/launch (GEMM kernel only)", "traffic_source": note_b,
                              "algorithmic_bytes": (rows * 3072 + rows * 768) * 2 + 3072 * 768 * 4},
         }
+        if dp_diag is not None:                        # one entry per rank: what the data-parallel machinery did on it
+            res["data_parallel"] = dp_diag
         if not a.no_cpu_baseline and W == 1:           # reported baseline, rank 0 of the single-GPU run only
             res["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(res), flush=True)

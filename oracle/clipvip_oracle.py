@@ -40,6 +40,31 @@ class _RoundBoth(torch.autograd.Function):
         return g.to(ctx.dtype).to(g.dtype), None
 
 
+class _RoundValueOnly(torch.autograd.Function):
+    """value rounded, gradient passed through unrounded"""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        return t.to(dtype).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundGradOnly(torch.autograd.Function):
+    """value untouched, incoming gradient rounded"""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        ctx.dtype = dtype
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
 class _Rounding:
     """Optional storage-precision emulation.  With ``ROUND.dtype = torch.bfloat16`` every tensor the HIP path
     stores in bf16 (weights fed to GEMMs, LayerNorm outputs, q/k/v, attention output, softmax probabilities fed
@@ -49,6 +74,7 @@ class _Rounding:
     gradients are fp32 in the HIP path), which makes the emulation a tight reference for the backward.  Default: off."""
     dtype = None
     grads = False
+    attn_operands = True       # P and dS rounded where the attention kernels feed them to the matrix cores (prob / scores below)
     proxy_fp32 = True          # the HIP path keeps the M proxy rows of the video tower's residual stream in fp32 (functional.PROXY_SIDE)
 
     def resid(self, t: Tensor, size) -> Tensor:
@@ -60,6 +86,20 @@ class _Rounding:
             return t
         M = size[0]
         return torch.cat([t[:, :M], self(t[:, M:])], dim=1)
+
+    def prob(self, w: Tensor) -> Tensor:
+        """softmax probabilities as the attention kernels feed them to the matrix cores: P is rounded to the storage dtype for P.V
+        (forward) and for dV = P^T.dO (backward, the same rounded P); its gradient dP = dO.V^T stays in fp32 accumulators"""
+        if self.dtype is None or not self.attn_operands:
+            return w
+        return _RoundValueOnly.apply(w, self.dtype) if w.requires_grad else w.to(self.dtype).to(w.dtype)
+
+    def scores(self, s: Tensor) -> Tensor:
+        """the attention scores: never stored (fp32 accumulators), but their GRADIENT dS = P o (dP - delta) is the matrix-core
+        operand of dQ = dS.K and dK = dS^T.Q and is rounded to the storage dtype there"""
+        if self.dtype is None or not self.attn_operands or not (self.grads and s.requires_grad):
+            return s
+        return _RoundGradOnly.apply(s, self.dtype)
 
     def __call__(self, t: Tensor, grad: bool = True) -> Tensor:
         if self.dtype is None:
@@ -147,9 +187,9 @@ def proxy_attention_core(q: Tensor, k: Tensor, v: Tensor, size: Tuple[int, int, 
     vp = v[:, :, :M].unsqueeze(2).expand(B, h, N, M, dh)
     kk = torch.cat([kp, kf], dim=3)                      # [B,h,N,M+L,dh]
     vv = torch.cat([vp, vf], dim=3)
-    w = torch.softmax(qf @ kk.transpose(-1, -2), dim=-1)  # [B,h,N,L,M+L]
+    w = ROUND.prob(torch.softmax(ROUND.scores(qf @ kk.transpose(-1, -2)), dim=-1))  # [B,h,N,L,M+L]
     of = (w @ vv).reshape(B, h, N * L, dh)
-    wp = torch.softmax(q[:, :, :M] @ k.transpose(-1, -2), dim=-1)  # [B,h,M,S]
+    wp = ROUND.prob(torch.softmax(ROUND.scores(q[:, :, :M] @ k.transpose(-1, -2)), dim=-1))  # [B,h,M,S]
     op = wp @ v
     return ROUND(torch.cat([op, of], dim=2))
 
@@ -168,18 +208,47 @@ def proxy_attention_core_masked(q: Tensor, k: Tensor, v: Tensor, size: Tuple[int
     return torch.softmax(s, dim=-1) @ v
 
 
+class _MaskedCoreStorageEmulation(torch.autograd.Function):
+    """softmax(q k^T + mask) v with the BACKWARD written the way the attention kernels compute it (flash-attention form), for the
+    storage-precision emulation only (ROUND.dtype set and ROUND.grads): the probabilities are recomputed, the row term is
+    delta = rowsum(dO o O) with the STORED (rounded) output O -- autograd's softmax backward uses sum_j P dP, i.e. the unrounded
+    output; the two differ by dO . (O_stored - O), which does not cancel over the keys of a row -- and P / dS enter the matrix
+    products rounded.  Forward values are those of the plain expression."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, dtype):
+        s = q @ k.transpose(-1, -2) + mask
+        p = torch.softmax(s, dim=-1)
+        o = (p.to(dtype).to(p.dtype) @ v).to(dtype).to(p.dtype)
+        ctx.save_for_backward(q, k, v, mask, o)
+        ctx.dtype = dtype
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, mask, o = ctx.saved_tensors
+        rnd = lambda t: t.to(ctx.dtype).to(t.dtype)
+        do = rnd(do)
+        p = torch.softmax(q @ k.transpose(-1, -2) + mask, dim=-1)
+        dp = do @ v.transpose(-1, -2)
+        delta = (do * o).sum(-1, keepdim=True)
+        ds = rnd(p * (dp - delta))
+        return ds @ k, ds.transpose(-1, -2) @ q, rnd(p).transpose(-1, -2) @ do, None, None
+
+
 def masked_attention_core(q: Tensor, k: Tensor, v: Tensor, pad_mask: Optional[Tensor]) -> Tensor:
     """Text-tower attention on [B,h,S,dh]: additive -inf causal mask (CLIP_ViP.py:788-797)
     plus additive finfo.min padding mask (_expand_mask, :50-61), both added to the scores
     before softmax (:286-304)."""
     B, h, S, dh = q.shape
-    s = q @ k.transpose(-1, -2)
-    causal = torch.full((S, S), float("-inf"), dtype=s.dtype, device=s.device).triu(1)
-    s = s + causal
+    add = torch.full((S, S), float("-inf"), dtype=q.dtype, device=q.device).triu(1)
     if pad_mask is not None:
-        inv = 1.0 - pad_mask.to(s.dtype)[:, None, None, :]
-        s = s + inv.masked_fill(inv.bool(), torch.finfo(s.dtype).min)
-    return ROUND(torch.softmax(s, dim=-1) @ v)
+        inv = 1.0 - pad_mask.to(q.dtype)[:, None, None, :]
+        add = add + inv.masked_fill(inv.bool(), torch.finfo(q.dtype).min)
+    if ROUND.dtype is not None and ROUND.grads and ROUND.attn_operands and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _MaskedCoreStorageEmulation.apply(q, k, v, add.expand(B, 1, S, S) if add.dim() == 4 else add, ROUND.dtype)
+    s = ROUND.scores(q @ k.transpose(-1, -2)) + add
+    return ROUND(ROUND.prob(torch.softmax(s, dim=-1)) @ v)
 
 
 def attention_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int,

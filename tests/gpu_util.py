@@ -52,10 +52,17 @@ def bf16_round(t: torch.Tensor) -> torch.Tensor:
 #       *_ref / *_e2e  free-running against the reference's fp32 values: the whole bf16 storage noise of 12 layers.
 # The entries above 2e-2 are (a) free-running trajectories (two bf16 realisations of a 12-layer network decorrelate: the oracle's
 # own bf16 emulation is as far from fp32 as this build is) and (b) `grad_emu_small` / `grad_ref_1d`: parameter gradients of the
-# 32-token text tower, sums of a few hundred signed bf16-rounded rows that largely cancel -- in the last layer only the pooled EOT
-# rows (2 at batch 2, 8 at batch 8) carry gradient.  Batch 8 brings the 1-D gradients vs the reference from 1.4e-1 to 9.2e-2 and the
-# bulk of the teacher-forced text gradients to 2-4e-2; the worst stays a last-layer bias (7.5e-2: eight rows).  The kernels
-# underneath are held to 1e-2..2e-2 against fp64 in tests/test_attention_gpu.py / test_gemm_gpu.py.
+# 32-token text tower.  What `grad_emu_small` can resolve was measured in round 5 (profiles/r05j_text_gradient_gate_evidence.txt,
+# tools/grad_scatter_study.py): an accumulation-order difference (one fp32 ulp in front of the bf16 roundings) moves these gradients
+# by <= 6e-3 at batch 8 -- it is NOT what the gate absorbs; two correct FORMULATIONS of the attention backward on identical inputs
+# (autograd's row term sum_j P dP against the kernels' flash-attention row term rowsum(dO o O) with the stored bf16 output, P / dS
+# rounded as matrix-core operands) differ by 4.4e-2 (batch 8) / 5.5e-2 (batch 2) on the q_proj / k_proj gradients -- dS rows sum to
+# zero and the row term is where a 2^-9 rounding does not cancel.  The GPU run shows exactly that set (q/k/v projections and
+# layer_norm1.bias behind them) at <= 6.8e-2 against either oracle formulation, everything outside the attention block <= 1.8e-2.
+# The raw LOGITS (cosines x e^4.6 ~ 100) are NOT inside north_star's 2e-2: |d cos| <= 6.7e-4 at the bench batch is 6.7e-2 on a logit;
+# the reference's own torch.autocast(bfloat16) run moves its logits by 3e-2..1e-1 against its fp32 run (`ref_bf16` in the fixtures),
+# so the gates sit on the cosines (`cos_abs`) and on the loss relative to its value (`loss_rel`, north_star's 2e-2), as SURVEY 7(iii) anticipated.
+# The kernels underneath are held to 1e-2..2e-2 against fp64 in tests/test_attention_gpu.py / test_gemm_gpu.py.
 TOL = {
     "features_abs": 2e-2,          # north_star's bound; only the tiny widened-weight fixture needs more than 2e-3 (5.1e-3 measured)
     "features_abs_full": 2e-3,     # |vis - ref|, |txt - ref| at every real architecture (cfg1..4, b8): vis <= 6.8e-4, txt <= 1.1e-3
@@ -71,7 +78,8 @@ TOL = {
     "hidden_emu_e2e": 3e-2,        # free-running 12-layer trajectories vs the emulation: 2.1e-2
     "hidden_ref": 3.5e-2,          # hidden-state rows vs reference fp32: 2.3e-2
     "grad_emu": 2e-2,              # teacher-forced: dx and every video-tower parameter gradient: <= 1.7e-2 (batch 8: 1.2e-2)
-    "grad_emu_small": 1e-1,        # teacher-forced text-tower parameter gradients: <= 6.6e-2 at batch 2, 7.5e-2 at batch 8 (bulk 2-4e-2)
+    "grad_emu_small": 1e-1,        # teacher-forced text-tower parameter gradients: <= 6.8e-2 (attention block; formulation scatter 4.4-5.5e-2
+                                   # measured on the CPU, see above), <= 1.8e-2 outside it
     "grad_ref_2d": 7.5e-2,         # weight gradients vs reference fp32, free-running: <= 5.0e-2
     "grad_ref_1d": 2.5e-1,         # 1-D gradients vs reference fp32, free-running: <= 1.7e-1 at batch 2, 9.2e-2 at batch 8
 }

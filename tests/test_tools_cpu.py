@@ -88,3 +88,46 @@ def test_workload_module_matches_the_oracle_definitions():
             assert a.dtype == b.dtype and torch.equal(a, b)
     for args in ((12, 224, 32, 16), (8, 448, 32, 16), (2, 224, 16, 32)):
         assert Wk.flops_per_pair(*args) == O.flops_per_pair(*args)
+
+
+def test_kernel_by_grid_separates_the_shapes_of_one_kernel(tmp_path):
+    """tools/kernel_by_grid.py: one row per (kernel, workgroup count) of a rocprofv3 kernel trace -- the 888-workgroup fc1 launches
+    are read apart from the 444-workgroup half-batch launches of the same kernel"""
+    import csv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kbg", os.path.join(ROOT, "tools", "kernel_by_grid.py"))
+    kbg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kbg)
+    name = "void (anonymous namespace)::gemm256_kernel<false, false>(xpgemm::KParams)"
+    rows = [dict(Kernel_Name=name, Start_Timestamp=0, End_Timestamp=118000 + 2000 * i, Workgroup_Size_X=512, Workgroup_Size_Y=1,
+                 Workgroup_Size_Z=1, Grid_Size_X=888 * 512, Grid_Size_Y=1, Grid_Size_Z=1) for i in range(3)]
+    rows += [dict(Kernel_Name=name, Start_Timestamp=0, End_Timestamp=96000, Workgroup_Size_X=512, Workgroup_Size_Y=1, Workgroup_Size_Z=1,
+                  Grid_Size_X=444 * 512, Grid_Size_Y=1, Grid_Size_Z=1)]
+    rows += [dict(Kernel_Name="ln_fwd", Start_Timestamp=0, End_Timestamp=13000, Workgroup_Size_X=256, Workgroup_Size_Y=1, Workgroup_Size_Z=1,
+                  Grid_Size_X=256 * 100, Grid_Size_Y=1, Grid_Size_Z=1)]
+    path = tmp_path / "trace.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    out = kbg.summarize(str(path), ("gemm256",))
+    assert [(r[2], r[4], r[5]) for r in out] == [(888, 3, 120.0), (444, 1, 96.0)]
+
+
+def test_bench_parses_what_rccl_reports_it_chose():
+    """bench.py's data-parallel diagnostics: channels / algorithm / protocol out of RCCL's NCCL_DEBUG=INFO (INIT,TUNING) lines"""
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = "\n".join([
+        "node:11:22 [3] NCCL INFO Channel 00/32 :    0   1   2   3   4   5   6   7",
+        "node:11:22 [3] NCCL INFO Channel 01/32 :    0   1   2   3   4   5   6   7",
+        "node:11:22 [3] NCCL INFO 32 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer",
+        "node:11:22 [3] NCCL INFO AllReduce: 67108864 Bytes -> Algo 1 proto 2 time 512.3",
+        "node:11:22 [3] NCCL INFO AllReduce: 67108864 Bytes -> Algo 1 proto 2 time 512.3",
+        "node:11:22 [3] NCCL INFO AllGather: 16384 Bytes -> Algo 1 proto 0 time 12.3"])
+    got = bench.parse_rccl_log(log)
+    assert got["coll_channels"] == 32 and got["ring_channel_lines"] == 2
+    assert got["tuning"] == [{"op": "AllReduce", "bytes": 67108864, "algo": "Ring", "proto": "Simple"},
+                             {"op": "AllGather", "bytes": 16384, "algo": "Ring", "proto": "LL"}]
+    assert bench.parse_rccl_log("")["coll_channels"] is None
