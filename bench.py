@@ -78,6 +78,7 @@ def parse():
                     "The line then carries `prefetch` and is NOT the contract's value.")
     ap.add_argument("--prefetch-dtype", default="fp32", choices=["fp32", "uint8"], help="host frames: normalised fp32 (57.8 MB per step at "
                     "cfg #2) or decoded uint8 (14.5 MB; normalisation inside the patch-GEMM loader)")
+    ap.add_argument("--bucket-mb", type=float, default=64.0, help="gradient bucket size of the all-reduce (MB of fp32 gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, join the process group, print the world size "
                     "measured by a collective and exit (no GPU work; backend gloo when there is no GPU) -- the launcher self-test")
@@ -379,7 +380,7 @@ def main():
     loss_fn = NCELearnableTempLoss()
     import xpretrain_amd.functional as XF
     # buckets aligned to the encoder layers: the native layer backward writes its gradients straight into bucket storage
-    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=float(os.environ.get("XPRETRAIN_BENCH_BUCKET_MB", "64")), average=True,
+    reducer = D.GradBucketReducer(model.parameters(), bucket_mb=a.bucket_mb, average=True,
                                   layout_groups=XF.layer_grad_groups(model), segments=D.tower_segments(model),
                                   wire_dtype={"fp32": None, "bf16": torch.bfloat16}[os.environ.get("XPRETRAIN_GRAD_WIRE", "fp32")])
     if forced and fmode == "gather":        # the gradient reducer stays out of it

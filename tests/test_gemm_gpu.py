@@ -130,7 +130,6 @@ def test_bad_arguments_raise():
 @pytest.fixture
 def force_gemm256(monkeypatch):
     monkeypatch.setenv("XPRETRAIN_GEMM256", "2")     # use the 256x256 family whenever its preconditions hold
-    monkeypatch.setenv("XPRETRAIN_GEMM256_SPLITK", "1")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -303,8 +302,8 @@ def test_gemm256_token_count_nn_and_f32():
 @pytest.mark.parametrize("M,N,K,split", [(3072, 768, 18848, 7), (768, 768, 18848, 27), (2304, 768, 9424, 9)])
 def test_dw_split_k_chunk_major_grid(M, N, K, split):
     """Weight-gradient shapes of the step (dW1, dWo, dWqkv): the split-K launch walks a 1-D grid over (k-chunk, tile) pairs,
-    chunk-major per XCD (csrc/gemm256.hip).  Against fp64, and bit-identical to the (tile, z) grid (XPRETRAIN_DW_CHUNK_MAJOR=0, read
-    once per process: a fresh process computes the same slabs) -- the mapping changes which CU computes a slab, never the slab."""
+    chunk-major per XCD (csrc/gemm256.hip).  Against fp64, and bit-identical to the (tile, z) grid (XPRETRAIN_DEBUG=dw_tile_major
+    in a fresh process: it computes the same slabs) -- the mapping changes which CU computes a slab, never the slab."""
     import os
     import subprocess
     import sys
@@ -323,7 +322,7 @@ def test_dw_split_k_chunk_major_grid(M, N, K, split):
             f"s = H.gemm(Y, X, {M}, {N}, {K}, a_kstrided=True, b_kstrided=True, split_k={split})\n"
             "assert torch.equal(s.cpu(), d['slabs'])\nprint('same')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, XPRETRAIN_DW_CHUNK_MAJOR="0"),
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, XPRETRAIN_DEBUG="dw_tile_major"),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "same" in out.stdout, out.stderr[-1500:]
 

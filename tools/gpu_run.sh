@@ -1,0 +1,48 @@
+#!/bin/bash
+# One runner for every GPU-box call (replaces the per-call scripts of rounds 3-5 under tools/runs/; what each round ran is listed
+# in profiles/README.md next to the files it produced).  Run through gpurun from the repository root, tasks chained with ';':
+#
+#   gpurun -- 'bash tools/gpu_run.sh r05z tests; bash tools/gpu_run.sh r05z bench --steps 20; bash tools/gpu_run.sh r05z profile'
+#
+#   tests   [pytest args]          python -m pytest tests -m gpu -q [args]            -> gpurun_out/<tag>/pytest.log
+#   bench   [bench.py args]        the bench line                                     -> gpurun_out/<tag>/bench.json
+#   ab      <rounds> <variant...>  tools/instep_ab.py, interleaved whole-step A/B     -> gpurun_out/<tag>/ab.txt
+#   kernels [gemm|gemmfwd|ln|attn] tools/bench_kernels.py (sustained clocks)          -> gpurun_out/<tag>/kernels.txt
+#   profile [bench.py args]        rocprofv3 --kernel-trace --stats of bench.py: per-kernel stats + one row per (kernel, grid)
+#                                                                                     -> gpurun_out/<tag>/{kernel_stats.csv,kernel_by_grid.txt,bench_under_rocprof.json}
+#   pmc                            PMC passes of the 256-wide GEMM family (tools/pmc_gemm256.sh)  -> gpurun_out/<tag>_pmc_gemm256.json
+#   timeline [shapes]              per-tile timeline of single GEMM launches (tools/gemm_timeline.py) -> gpurun_out/<tag>/timeline.txt
+#   vendor  [args]                 in-step calibration against the vendor library (tools/vendor_instep.py) -> gpurun_out/<tag>/vendor_instep.txt
+set -u
+TAG=${1:?tag}; TASK=${2:?task}; shift 2
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R; O=$R/gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+case $TASK in
+  tests)
+    timeout 1500 python -m pytest tests -m gpu -q "$@" > $O/pytest.log 2>&1; echo "pytest exit $?"; tail -4 $O/pytest.log ;;
+  bench)
+    timeout 900 python bench.py "$@" 2> $O/bench.err | grep "^{" > $O/bench.json
+    python3 -c "
+import json; d=json.load(open('$O/bench.json')); r=d['roofline']; b=d['roofline_bwd']
+print('bench', d['value'], 'pairs/s', d['ms_per_step'], 'ms/step; vit fwd', d['vit_forward_train_mode_ms'], d['vit_forward_ms'], '; roofline', r['frac'], r['kernel_ms'], '; bwd', b['frac'], b['kernel_ms'], '; cpu', d.get('cpu_baseline', {}).get('value'))" ;;
+  ab)
+    ROUNDS=$1; shift
+    timeout 3000 python tools/instep_ab.py --rounds $ROUNDS --steps 20 --out $O/ab.txt "$@" 2>&1 | tail -$(( $# + 2 )) ;;
+  kernels)
+    timeout 600 python tools/bench_kernels.py "${1:-all}" 2>&1 | grep -v amdgpu.ids | tee $O/kernels.txt ;;
+  profile)
+    rm -rf /tmp/prof_$TAG
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $O/bench_under_rocprof.log 2>&1
+    grep "^{" $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
+    cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+    python3 tools/kernel_by_grid.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) > $O/kernel_by_grid.txt
+    head -12 $O/kernel_by_grid.txt | cut -c1-150 ;;
+  pmc)
+    bash tools/pmc_gemm256.sh $TAG > $O/pmc.log 2>&1; tail -1 $O/pmc.log | cut -c1-300 ;;
+  timeline)
+    timeout 300 python tools/gemm_timeline.py "$@" 2>&1 | grep -v amdgpu.ids | cut -c1-1500 | tee $O/timeline.txt ;;
+  vendor)
+    timeout 900 python tools/vendor_instep.py --out $O/vendor_instep.txt "$@" 2>&1 | grep -v amdgpu.ids | tail -48 ;;
+  *) echo "unknown task $TASK"; exit 2 ;;
+esac

@@ -4,7 +4,7 @@
     python tools/instep_ab.py [--rounds 3] [--steps 20] [--out gpurun_out/ab.txt] VARIANT [VARIANT ...]
 
 VARIANT = name[@tree][:ENV=value[,ENV=value...]][/--bench-flag=value ...]
-          e.g.   default   nofwd3:XPRETRAIN_ATTN_FWD3=0   r2@_ab_r2   pf:XPRETRAIN_BENCH_FORCE_COLLECTIVES=1/--prefetch=1/--prefetch-dtype=uint8
+          e.g.   default   one:XPRETRAIN_FWD_SPLIT=0   r2@_ab_r2   pf:XPRETRAIN_BENCH_FORCE_COLLECTIVES=1/--prefetch=1/--prefetch-dtype=uint8
           (tree: another checkout of this repository with its library built, relative to the repository root; default: this one)
 
 Every round runs `python bench.py --no-cpu-baseline --steps N` once per variant, in the order given; the table lists pairs/s,

@@ -2,7 +2,7 @@
 """Socket power and shader clock while ONE kernel shape runs back to back for a few seconds (rocm-smi polled from a thread).
 The GEMMs of the video tower are power-limited (tools/clock_probe.hip): at the cap, the wall time of a launch IS its energy.
 
-    python tools/power_probe.py [seconds per shape]      (XPRETRAIN_GEMM256W / _ABL etc. select the kernel as usual)"""
+    python tools/power_probe.py [seconds per shape]      (shapes: fc1 and fc2 forward of cfg #2)"""
 import json
 import subprocess
 import sys

@@ -146,11 +146,11 @@ def make_aggressors(dev):
         H.gemm(dpre, W, R, Dt, Dff, b_kstrided=True)
 
     def gemm_text_noglds():
-        os.environ["XPRETRAIN_GEMM_NO_GLDS"] = "1"
+        os.environ["XPRETRAIN_DEBUG"] = "gemm_no_glds"          # (read by the library at every call: csrc/common.cpp::xp_debug_flag)
         try:
             H.gemm(dpre, W, R, Dt, Dff, b_kstrided=True)
         finally:
-            del os.environ["XPRETRAIN_GEMM_NO_GLDS"]
+            del os.environ["XPRETRAIN_DEBUG"]
 
     dpre_s, W_s = rn(R, 128, sc=1e-3).to(BF), rn(128, Dt, sc=0.02).to(BF)
     dpre_l, W_l = rn(R, 16384, sc=1e-3).to(BF), rn(16384, Dt, sc=0.02).to(BF)
@@ -163,11 +163,11 @@ def make_aggressors(dev):
         H.gemm(dpre_l, W_l, R, Dt, 16384, b_kstrided=True)
 
     def gemm_text_slowepi():
-        os.environ["XPRETRAIN_GEMM_SLOW_EPI"] = "1"
+        os.environ["XPRETRAIN_DEBUG"] = "gemm_slow_epi"
         try:
             H.gemm(dpre, W, R, Dt, Dff, b_kstrided=True)
         finally:
-            del os.environ["XPRETRAIN_GEMM_SLOW_EPI"]
+            del os.environ["XPRETRAIN_DEBUG"]
 
     def gemm_text_fwd_k16384():
         H.gemm(dpre_l, rn(Dt, 16384, sc=0.02).to(BF) if False else W_l2, R, Dt, 16384)

@@ -13,7 +13,7 @@ import time
 sys.path.insert(0, os.getcwd())
 mode = sys.argv[2] if len(sys.argv) > 2 else "plain"
 if mode == "forced_nocomm":
-    os.environ["XPRETRAIN_DEBUG_REDUCER"] = "nocomm"
+    os.environ["XPRETRAIN_DEBUG"] = ",".join(filter(None, [os.environ.get("XPRETRAIN_DEBUG", ""), "no_comm"]))
 import torch  # noqa: E402
 import bench as B  # noqa: E402
 from xpretrain_amd import workload as O  # noqa: E402  (config + synthetic inputs)

@@ -2,7 +2,7 @@
 """In-step calibration of the 256-wide GEMM kernels against the vendor library (VERDICT r3, next #1a).  TOOLS ONLY: nothing in the
 product path calls the vendor library.
 
-The training step of bench.py runs op by op (XPRETRAIN_LAYER_CALLS=0, so that every xp_gemm call of the encoder layers passes
+The training step of bench.py runs op by op (XPRETRAIN_DEBUG=op_by_op, so that every xp_gemm call of the encoder layers passes
 through hip_ops.gemm); every video-tower GEMM (token dimension >= 4096) gets a SHADOW: the same product computed by torch.mm
 (hipBLASLt) on the same operands into a scratch buffer, launched right before or right after our kernel on the same stream.  Both
 launches are bracketed by HIP events on that stream.  The step is longer than the real one (twice the GEMM work), but each vendor
@@ -20,7 +20,7 @@ import os
 import statistics
 import sys
 
-os.environ["XPRETRAIN_LAYER_CALLS"] = "0"
+os.environ["XPRETRAIN_DEBUG"] = ",".join(filter(None, [os.environ.get("XPRETRAIN_DEBUG", ""), "op_by_op"]))
 sys.path.insert(0, os.getcwd())
 import torch  # noqa: E402
 import bench as B  # noqa: E402

@@ -185,7 +185,12 @@ def lib():
     return _lib
 
 
-DEBUG_SYNC = bool(int(os.environ.get("XPRETRAIN_DEBUG_SYNC", "0")))
+# XPRETRAIN_DEBUG=flag[,flag...]: the debug / test facilities (csrc/common.cpp lists the library's flags).  Python side:
+#   sync      synchronise and check the device after every library call (errors then surface at the call that caused them)
+#   op_by_op  encoder layers as separate operator calls instead of one C-ABI call per pass (the fingerprinting / calibration tools)
+#   no_comm   GradBucketReducer packs and tracks its buckets but skips the all-reduce calls (cost attribution on one GPU)
+DEBUG = frozenset(f for f in os.environ.get("XPRETRAIN_DEBUG", "").split(",") if f)
+DEBUG_SYNC = "sync" in DEBUG
 
 
 def check(rc, what):

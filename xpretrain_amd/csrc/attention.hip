@@ -1146,12 +1146,11 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
   p.ws2 = (float*)g_attn_trace;
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)(B * H * N);
-  static const int fwd3 = getenv("XPRETRAIN_ATTN_FWD3") ? atoi(getenv("XPRETRAIN_ATTN_FWD3")) : 1;     // debug switch: 0 = always the 7-wave kernel
   // the persistent kernel: proxy problems that fit one LDS group, no padding mask, at most 16 proxy rows (its proxy x proxy mask
   // lives in query tile 0 / key sub-tile 0 only), and a device that grants the 104 KiB dynamic-LDS opt-in (configured per device)
-  bool use3 = fwd3 && mode == XP_ATTN_PROXY && p.R <= FG && p.M <= 16 && !pad_mask;
+  bool use3 = mode == XP_ATTN_PROXY && p.R <= FG && p.M <= 16 && !pad_mask;
   // the multi-group persistent kernel: proxy problems wider than one LDS group (448^2 frames), same conditions otherwise
-  bool use4 = fwd3 && mode == XP_ATTN_PROXY && p.R > FG && p.M <= 16 && !pad_mask;
+  bool use4 = mode == XP_ATTN_PROXY && p.R > FG && p.M <= 16 && !pad_mask;
   int ncu = 256;
   if (use3 || use4) {
     static std::mutex mu;
@@ -1174,8 +1173,7 @@ extern "C" int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ld
     }
   }
   if (use3) {
-    const int fgrid = fwd3 > 1 ? fwd3 : ncu;              // (XPRETRAIN_ATTN_FWD3=<n>: grid size, for experiments)
-    attn_fwd3_kernel<<<(unsigned)(p.nprob < fgrid ? p.nprob : fgrid), F3THR, F3_LDS, st>>>(p);
+    attn_fwd3_kernel<<<(unsigned)(p.nprob < ncu ? p.nprob : ncu), F3THR, F3_LDS, st>>>(p);
   } else if (use4) {
     attn_fwd4_kernel<<<(unsigned)ncu, F3THR, F3_LDS, st>>>(p);      // persistent: one workgroup per CU (ncu is a multiple of 8 here)
   } else {

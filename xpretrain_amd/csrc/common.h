@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ------------------------------------------------------------------------------------------ errors
 void xp_set_error(const char* fmt, ...);   // thread-local message (common.cpp)
+bool xp_debug_flag(const char* name);      // XPRETRAIN_DEBUG=flag[,flag...] (common.cpp)
 
 #define XP_REQUIRE(cond, ...)                                  \
   do {                                                         \

@@ -431,7 +431,7 @@ void launch2(const XpGemmDesc* d, const KParams& kp, dim3 grid, hipStream_t st) 
 
 // The direct-to-LDS path needs dense, un-remapped operands whose tails the buffer bounds check can zero-fill.
 bool glds_ok(const XpGemmDesc* d, int esz) {
-  if (getenv("XPRETRAIN_GEMM_NO_GLDS")) return false;
+  if (xp_debug_flag("gemm_no_glds")) return false;
   if (d->a_grp != 0) return false;
   const int64_t ke = BKB / esz;
   const int64_t a_rows = d->a_kstrided ? d->K : d->M, b_rows = d->b_kstrided ? d->K : d->N;
@@ -746,7 +746,7 @@ extern "C" int xp_gemm(const XpGemmDesc* d, void* stream) {
 
 // fast epilogue (gemm_common.h): identity row map, 32-bit buffer offsets that cannot wrap for any row of the last tile
 bool xp_gemm_fast_epi_ok(const XpGemmDesc* d) {
-  if (getenv("XPRETRAIN_GEMM_SLOW_EPI")) return false;
+  if (xp_debug_flag("gemm_slow_epi")) return false;
   const int64_t esz = d->in_dtype == XP_BF16 ? 2 : 4, osz = d->out_dtype == XP_F32 ? 4 : esz, lim = (int64_t)EPI_OOB - 64;
   const int64_t rows = d->M + 256;
   const bool wide = d->N % 8 == 0 && d->ldc % 8 == 0 && (!d->resid || d->ldr % 8 == 0) && (!d->aux || d->ldaux % 8 == 0);

@@ -383,16 +383,12 @@ bool xp_gemm256_wanted(const XpGemmDesc* d, int split) {
 // (PMC, profiles/r04s_pmc_gemm256.json).  Rule: the fewest column groups (1, 2 or 4 -- they must tile the 8 XCDs) whose weight
 // share is <= 3.6 MB, groups of at least 4 columns (the K = 3072 problems with 3 tile columns lose with a 2 + 1 split: their
 // concurrent tiles move through k together, the live weight window is small): two groups of 6 columns at N = 3072 (2.4 MB resident
-// per XCD, activations fetched twice), one group everywhere else.  XPRETRAIN_GEMM256_COLGROUPS=n forces n groups (A/B).
+// per XCD, activations fetched twice), one group everywhere else.  In the step: -0.07 ms against one group, level with four
+// (profiles/r05k_in_step_ab_l2_column_groups.txt); fabric fetch of fc1: profiles/r05l_pmc_gemm256.json.
 int xp_gemm256_group_n(const XpGemmDesc* d, int tiles_n) {
-  static const int forced = getenv("XPRETRAIN_GEMM256_COLGROUPS") ? atoi(getenv("XPRETRAIN_GEMM256_COLGROUPS")) : 0;
   int groups = 1;
-  if (forced > 0) groups = forced;
-  else {
-    const int64_t wbytes = (int64_t)tiles_n * TN * d->K * 2;
-    while (groups < 4 && wbytes / groups > (int64_t)3600 * 1024 && tiles_n / (groups * 2) >= 4) groups *= 2;
-  }
-  if (groups > tiles_n) groups = tiles_n;
+  const int64_t wbytes = (int64_t)tiles_n * TN * d->K * 2;
+  while (groups < 4 && wbytes / groups > (int64_t)3600 * 1024 && tiles_n / (groups * 2) >= 4) groups *= 2;
   return (int)cdiv(tiles_n, groups);
 }
 
@@ -409,7 +405,7 @@ bool xp_gemm256_try(const XpGemmDesc* d, const xpgemm::KParams& kp_base, hipStre
   if (cdiv(k_last, KE) < 2) return false;                                         // the pipeline needs >= 2 k-tiles
   kp.tiles_m = (int)cdiv(d->M, TM); kp.tiles_n = (int)cdiv(d->N, TN);
   kp.group_n = split > 1 ? kp.tiles_n : xp_gemm256_group_n(d, kp.tiles_n);
-  static const bool chunk_major = !getenv("XPRETRAIN_DW_CHUNK_MAJOR") || atoi(getenv("XPRETRAIN_DW_CHUNK_MAJOR")) != 0;   // (A/B switch)
+  const bool chunk_major = !xp_debug_flag("dw_tile_major");      // (test facility: the (tile, z) grid of rounds 1-3, bit-identical slabs)
   kp.flat_split = (split > 1 && chunk_major) ? split : 0;
   dim3 grid(kp.tiles_m * kp.tiles_n * (kp.flat_split ? split : 1), 1, kp.flat_split ? 1 : split);
   if (!d->a_kstrided && !d->b_kstrided)      return launch_one<false, false>(kp, grid, st);

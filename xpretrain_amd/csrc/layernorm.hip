@@ -331,7 +331,7 @@ extern "C" int xp_layernorm_fwd_side(const void* x, int64_t ldx, const float* ga
   XP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "xp_layernorm_fwd: ld must be a multiple of 4");
   const int blocks = (int)(cdiv(rows, WAVES) < 4096 ? cdiv(rows, WAVES) : 4096);
   hipStream_t st = (hipStream_t)stream;
-  static const bool half_rows = !getenv("XPRETRAIN_LN_HALFWAVE") || atoi(getenv("XPRETRAIN_LN_HALFWAVE")) != 0;      // (A/B switch)
+  const bool half_rows = true;
   const bool wide16 = dtype == XP_BF16 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
                       (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)x_side | (uintptr_t)y_side) & 15) == 0;
   if (half_rows && wide16) {

@@ -122,8 +122,8 @@ def gather_features(vis: torch.Tensor, txt: torch.Tensor, verify_identical: bool
     return gather_packed(vis, txt, verify_identical=verify_identical)
 
 
-# XPRETRAIN_DEBUG_REDUCER=nocomm: the reducer packs and tracks its buckets but skips the all-reduce calls (cost attribution on one GPU)
-_DEBUG_NO_COMM = os.environ.get("XPRETRAIN_DEBUG_REDUCER", "") == "nocomm"
+# XPRETRAIN_DEBUG=no_comm: the reducer packs and tracks its buckets but skips the all-reduce calls (cost attribution on one GPU)
+_DEBUG_NO_COMM = "no_comm" in os.environ.get("XPRETRAIN_DEBUG", "").split(",")
 
 
 class _NoWork:

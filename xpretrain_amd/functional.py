@@ -170,10 +170,10 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, 
 
 
 # ------------------------------------------------------------------------------------------ encoder layer, native sequencing
-# XPRETRAIN_LAYER_CALLS=1 (default): one C-ABI call per layer pass (xp_encoder_layer_fwd / _bwd, csrc/layer.hip) -- the same
-# entry points in the same order with the same arguments as the op-by-op path below, issued from native code; =0 keeps the
+# LAYER_CALLS (default): one C-ABI call per layer pass (xp_encoder_layer_fwd / _bwd, csrc/layer.hip) -- the same entry points in
+# the same order with the same arguments as the op-by-op path below, issued from native code; XPRETRAIN_DEBUG=op_by_op keeps the
 # op-by-op path (tools/determinism_hunt.py fingerprints every call of it; tests compare the two paths bit for bit).
-LAYER_CALLS = os.environ.get("XPRETRAIN_LAYER_CALLS", "1") != "0"
+LAYER_CALLS = "op_by_op" not in L.DEBUG
 _DT_CODE = {torch.bfloat16: L.XP_BF16, torch.float32: L.XP_F32}
 _NULLCTX = contextlib.nullcontext()
 _ES = {torch.bfloat16: 2, torch.float32: 4}
@@ -252,12 +252,12 @@ def _native_ok(x, vecs, mats, pad_mask) -> bool:
 # XPRETRAIN_FWD_SPLIT=0: the whole batch as one chain (A/B switch for the two half-batch chains of the video tower's forward)
 FWD_SPLIT = os.environ.get("XPRETRAIN_FWD_SPLIT", "1") != "0"
 FWD_SPLIT_MIN_ROWS = 8192          # below this a half-batch launch no longer fills the chip beside its twin
-# XPRETRAIN_FWD_SPLIT_STREAM: which stream the second chain runs on.  "side" (default): the library's weight-gradient stream, idle
+# FWD_SPLIT_STREAM (module attribute; tools set it): which stream the second chain runs on.  "side": the library's weight-gradient stream, idle
 # during the forward (xp_side_stream) -- the step then touches main + text tower + side = three streams, as before the split.  "own":
 # a torch stream of its own.  Same speed on one GPU (15.75 vs 15.75-15.79 ms per step, profiles/r04w_in_step_ab_second_chain_stream.txt);
 # the fewer streams a step touches the better it survives the streams a collective library or a prefetcher adds: a fifth stream
 # touched by the step cost 5 ms per step on this runtime, a fourth nothing (profiles/r04u_stream_count_probe.txt).
-FWD_SPLIT_STREAM = os.environ.get("XPRETRAIN_FWD_SPLIT_STREAM", "side")
+FWD_SPLIT_STREAM = "side"
 _SPLIT_STREAMS = {}
 
 
@@ -600,8 +600,8 @@ def with_side_rows(x: torch.Tensor, side: Optional[torch.Tensor], B: int, S: int
     return h
 
 
-# XPRETRAIN_PATCH_GATHER=0: always materialise the patch matrix (A/B switch for the on-the-fly gather in the GEMM loader)
-PATCH_GATHER = os.environ.get("XPRETRAIN_PATCH_GATHER", "1") != "0"
+# False: always materialise the patch matrix instead of gathering it in the GEMM loader (module attribute: tests compare the two)
+PATCH_GATHER = True
 
 
 # ------------------------------------------------------------------------------------------ embeddings
