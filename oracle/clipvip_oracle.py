@@ -74,7 +74,11 @@ class _Rounding:
     gradients are fp32 in the HIP path), which makes the emulation a tight reference for the backward.  Default: off."""
     dtype = None
     grads = False
-    attn_operands = True       # P and dS rounded where the attention kernels feed them to the matrix cores (prob / scores below)
+    attn_operands = False      # True: the attention backward in the kernels' flash-attention FORM (row term from the stored output, P / dS
+                               # rounded as matrix-core operands: prob / scores / _MaskedCoreStorageEmulation below).  Off for the parity gates:
+                               # the oracle's stored output is another bf16 realisation than the kernel's, so mirroring the form adds the
+                               # oracle's own row-term noise to the comparison instead of removing the kernel's (measured: text q_proj gradients
+                               # 6.7e-2 -> 1.2e-1 at batch 2); tools/grad_scatter_study.py switches it on to measure the distance between the forms
     proxy_fp32 = True          # the HIP path keeps the M proxy rows of the video tower's residual stream in fp32 (functional.PROXY_SIDE)
 
     def resid(self, t: Tensor, size) -> Tensor:
