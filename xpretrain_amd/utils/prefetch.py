@@ -1,6 +1,6 @@
 """``PrefetchLoader``: the host->device hand-over of the reference's training loop (``src/datasets/dataloader.py:79-157``: batch
 i+1 is copied to the GPU on a side stream while step i computes; ``next()`` makes the compute stream wait for the copy and
-``record_stream``s the tensors).  Same class name, constructor and iteration protocol, so ``run_pretrain.py:278-279`` keeps its lines.
+``record_stream``s the tensors).  Same class name, constructor and iteration protocol, so ``run_pretrain.py:245-247`` keeps its lines.
 
 Differences, all on the copy side: host tensors are pinned once per batch (a pageable source makes ``cuda(non_blocking=True)`` a
 synchronous copy), and the copy stream can be handed in (``stream=``): ``stream="text"`` reuses the stream ``CLIPModel.forward`` runs
