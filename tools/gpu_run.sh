@@ -33,11 +33,13 @@ print('bench', d['value'], 'pairs/s', d['ms_per_step'], 'ms/step; vit fwd', d['v
     timeout 600 python tools/bench_kernels.py "${1:-all}" 2>&1 | grep -v amdgpu.ids | tee $O/kernels.txt ;;
   profile)
     rm -rf /tmp/prof_$TAG
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $O/bench_under_rocprof.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python bench.py --steps 10 --warmup 3 --profile-run "$@" > $O/bench_under_rocprof.log 2>&1
     grep "^{" $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
     cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
     python3 tools/kernel_by_grid.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) > $O/kernel_by_grid.txt
-    head -12 $O/kernel_by_grid.txt | cut -c1-150 ;;
+    grep -E "^kernel|gemm256_kernel<false, false> +888" $O/kernel_by_grid.txt | cut -c1-150
+    python3 -c "
+import json; d=json.load(open('$O/bench_under_rocprof.json')); print('the same run: roofline.kernel_ms (HIP events, median of the in-step fc1 launches) =', d['roofline']['kernel_ms'], 'ms;', d['ms_per_step'], 'ms/step under the profiler')" ;;
   pmc)
     bash tools/pmc_gemm256.sh $TAG > $O/pmc.log 2>&1; tail -1 $O/pmc.log | cut -c1-300 ;;
   timeline)
