@@ -342,7 +342,8 @@ def main():
     if a.gpus > 1 or os.environ.get("XPRETRAIN_BENCH_FORCE_COLLECTIVES", "") in ("1", "gather", "reducer"):
         # what RCCL actually chose (channels, algorithm, protocol per message size) goes to a per-process file that dp_diagnostics()
         # parses after the timed region: the first multi-GPU run then shows whether the defaults above were honoured
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN"):      # (the image exports NCCL_DEBUG=VERSION)
+            os.environ["NCCL_DEBUG"] = "INFO"
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
         os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "xp_bench_rccl.%h.%p.log"))
     local_rank = D.init_from_env()
