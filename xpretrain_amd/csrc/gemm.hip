@@ -797,7 +797,13 @@ extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) {
   const int esz = d->in_dtype == XP_BF16 ? 2 : 4;
   const int64_t ke = BKB / esz;
   const int64_t t256 = cdiv(d->M, 256) * cdiv(d->N, 256);
-  const int64_t cus = g_cu_budget;
+  // Split-K launches (the weight gradients) fill at most XP_SPLITK_FILL CUs, not the chip: they run on the weight-gradient stream
+  // BESIDE the dX chain, which takes whatever CUs they leave, and every split costs an fp32 slab written and read again -- at a
+  // fill of 256 (splits 7 / 9 / 27) the slabs of one layer are 260 MB each way, 6.2 GB per step, more than the optimizer moves;
+  // at 176 (splits 4 / 6 / 19) they are 150 MB and every workgroup runs a 1.6x longer k loop per prologue / epilogue.
+  // Whole step, interleaved (profiles/r05s_in_step_ab_splitk_fill.txt): 15.55 -> 15.14 ms (fill 208: 15.35, 144: 15.31, 128: 15.29).
+  constexpr int64_t XP_SPLITK_FILL = 176;
+  const int64_t cus = g_cu_budget < XP_SPLITK_FILL ? g_cu_budget : XP_SPLITK_FILL;
   int64_t s0 = cus / t256 < d->K / 512 ? cus / t256 : d->K / 512;
   const int s256 = valid_split(d->K, s0, 64);
   if (xp_gemm256_wanted(d, s256)) return s256;
