@@ -44,8 +44,9 @@ def reserve_cus_for_collectives(n_channels: Optional[int] = None) -> int:
     """Tell the GEMM planning how many CUs RCCL's kernels take away beside the backward pass.  RCCL's gfx950 collective kernel
     (rcclGenericKernel in the librccl.so this image ships: 256 threads, 261-280 VGPRs + 17-32 AGPRs, 19.7 KB LDS -- llvm-readelf on
     its unbundled code object) runs ONE wave per SIMD, so a channel's workgroup owns a CU for as long as a bucket all-reduce lasts
-    and cannot share it with a 256x256-GEMM workgroup.  With the default budget of 256 CUs a 252-workgroup dW launch would spill 12
-    tiles into a second round.  ``n_channels`` defaults to $NCCL_MAX_NCHANNELS (bench.py sets it for its ranks), else 16.  Returns
+    and cannot share it with a 256x256-GEMM workgroup.  (Since round 5 the split-K planning fills at most 176 CUs anyway --
+    csrc/gemm.hip::XP_SPLITK_FILL -- so the budget only binds below that; it is still reported and still the place to tell the library.)
+    ``n_channels`` defaults to $NCCL_MAX_NCHANNELS (bench.py sets it for its ranks), else 16.  Returns
     the budget set.  No-op in a 1-rank run."""
     if world_size() == 1:
         return 256
