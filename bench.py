@@ -617,6 +617,10 @@ def main():
                                                   "stream it is launched on, xp_debug_gemm_timer); it runs beside the dX chain of the main stream, so the "
                                                   "duration is a shared-chip one" if dw1_in_step_ms else "30 isolated launches incl. the reduce"),
                              "kernel_ms_isolated_with_reduce": round(b_ms, 4), "frac_isolated_with_reduce": round(b_tf / PEAK_BF16_TFLOPS, 4),
+                             # the split-K planning fills at most 176 CUs on purpose (csrc/gemm.hip::XP_SPLITK_FILL: the launch runs beside the dX
+                             # chain and every split is an fp32 slab written and read again) -- `frac` is a whole-chip rate of a launch that holds
+                             # `workgroups` of the 256 CUs; `frac_of_held_cus` is the same time against the peak of the CUs it occupies
+                             "workgroups": 36 * dw1_split, "frac_of_held_cus": round(bw_tf / PEAK_BF16_TFLOPS * 256.0 / min(256, 36 * dw1_split), 4),
                              "traffic": tr_b, "traffic_unit": "bytes/launch (GEMM kernel only)", "traffic_source": note_b,
                              "algorithmic_bytes": (rows * 3072 + rows * 768) * 2 + 3072 * 768 * 4},
         }
