@@ -120,7 +120,7 @@ def time_dominant_kernels(dev, rows, D=768, Dff=3072, iters=30):
     dpre = (torch.randn(rows, Dff, device=dev) * 1e-3).to(bf)
     flops = 2.0 * rows * D * Dff
     ms_f = _time(lambda: H.gemm(A, W, rows, Dff, D, out=out, epilogue=L.EPI_BIAS_GELU, bias=bias, aux=aux), iters)
-    ms_b = _time(lambda: _wgrad(dpre, A, rows, Dff, D), iters)
+    ms_b = _time(lambda: _wgrad(dpre, A, rows, Dff, D, slack=True), iters)
     return {"fwd": (flops / (ms_f * 1e-3) / 1e12, ms_f), "bwd": (flops / (ms_b * 1e-3) / 1e12, ms_b)}
 
 
@@ -523,7 +523,7 @@ def main():
     if two_chains:
         fc1_two_chain_ms = timed_gemm(rows_ // 2, 3072, 768, L.EPI_BIAS_GELU, 0, 0, 1)
     # the dominant backward kernel where it runs: dW1 = dpre^T . h2 on the weight-gradient stream, beside the dX chain
-    dw1_split = XF._split_for(3072, 768, rows_, torch.bfloat16, (0, 0, 0))
+    dw1_split = XF._split_for(3072, 768, rows_, torch.bfloat16, (0, 0, 0), True)      # (a "slack" launch of the layer's backward: csrc/layer.hip)
     dw1_in_step_ms = timed_gemm(3072, 768, rows_, L.EPI_NONE, 1, 1, dw1_split)
     saved = XF.FWD_SPLIT
     XF.FWD_SPLIT = False
@@ -617,7 +617,7 @@ def main():
                                                   "stream it is launched on, xp_debug_gemm_timer); it runs beside the dX chain of the main stream, so the "
                                                   "duration is a shared-chip one" if dw1_in_step_ms else "30 isolated launches incl. the reduce"),
                              "kernel_ms_isolated_with_reduce": round(b_ms, 4), "frac_isolated_with_reduce": round(b_tf / PEAK_BF16_TFLOPS, 4),
-                             # the split-K planning fills at most 176 CUs on purpose (csrc/gemm.hip::XP_SPLITK_FILL: the launch runs beside the dX
+                             # the split-K planning fills at most 112 CUs here on purpose (csrc/gemm.hip::XP_SPLITK_FILL_SLACK: the launch runs beside the dX
                              # chain and every split is an fp32 slab written and read again) -- `frac` is a whole-chip rate of a launch that holds
                              # `workgroups` of the 256 CUs; `frac_of_held_cus` is the same time against the peak of the CUs it occupies
                              "workgroups": 36 * dw1_split, "frac_of_held_cus": round(bw_tf / PEAK_BF16_TFLOPS * 256.0 / min(256, 36 * dw1_split), 4),

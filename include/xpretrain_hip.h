@@ -102,6 +102,11 @@ int xp_gemm(const XpGemmDesc* desc, void* stream);
  * of workgroups of the kernel family xp_gemm will pick for `desc` (desc->split_k and the data pointers are
  * ignored).  The value is always accepted by xp_gemm (whole k-steps per slab, no empty slab); 1 = no split. */
 int32_t xp_gemm_auto_split(const XpGemmDesc* desc);
+/* The same for a split-K launch that has SLACK: it runs on another stream beside the caller's work and nothing waits for it soon --
+ * the first three weight-gradient GEMMs of an encoder layer's backward (fc2, fc1, out_proj: issued on the weight-gradient stream
+ * while the dX chain of the layer still has attention and two GEMMs to go); the last one (q/k/v) is what the layer's join waits
+ * for and takes xp_gemm_auto_split.  Fewer, longer slabs: less fp32 slab traffic beside the work it shares the chip with. */
+int32_t xp_gemm_auto_split_slack(const XpGemmDesc* desc);
 /* CUs the split-K planning may fill (64..256, default 256 or $XPRETRAIN_CU_BUDGET).  A data-parallel run lowers it by the number
  * of workgroups its collective library keeps resident during the backward pass (hvd.DistributedOptimizer's all-reduce,
  * run_pretrain.py:224-227,379; RCCL's gfx950 kernels own a CU per workgroup) so that a dW launch still fits one round. */

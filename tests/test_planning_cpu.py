@@ -32,6 +32,15 @@ def test_auto_split_cfg2_weight_gradients(M, N, K, expect):
     assert s == expect and _valid_split(K, s) and s * (-(-M // 256)) * (-(-N // 256)) <= 176
 
 
+@pytest.mark.parametrize("M,N,K,expect", [(768, 768, 18848, 12), (3072, 768, 18848, 3), (768, 3072, 18848, 3), (2304, 768, 18848, 4)])
+def test_auto_split_of_launches_with_slack(M, N, K, expect):
+    """xp_gemm_auto_split_slack: the first three weight-gradient GEMMs of a layer's backward (nothing waits for them soon) fill at most
+    112 CUs: fc2 / fc1 3 slabs, out_proj 12; never more slabs than the general plan"""
+    lib = L.lib()
+    s = lib.xp_gemm_auto_split_slack(C.byref(_desc(M, N, K)))
+    assert s == expect and _valid_split(K, s) and s <= lib.xp_gemm_auto_split(C.byref(_desc(M, N, K)))
+
+
 def test_auto_split_is_always_accepted():
     lib = L.lib()
     for M, N in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (768, 768), (256, 256), (3072, 768), (128, 96)]:

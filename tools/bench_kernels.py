@@ -49,7 +49,7 @@ def bench_gemm(fwd_only=False):
         print(f"gemm dX  {name:4s}: {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
         # dW[N,K] = dY^T X: the production path (functional._wgrad: split-K chosen by xp_gemm_auto_split + deterministic reduce)
         from xpretrain_amd.functional import _wgrad, _split_for
-        split = _split_for(N, K, M, bf, (0, 0, 0))
+        split = _split_for(N, K, M, bf, (0, 0, 0))        # (the general plan; fc2 / fc1 / out_proj run the "slack" plan inside a layer's backward)
         us = timeit(lambda: _wgrad(dY, A, M, N, K))
         print(f"gemm dW  {name:4s} split={split:2d} (auto): {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TFLOP/s")
         us = timeit(lambda: H.colsum(dY, M, N))

@@ -93,6 +93,7 @@ SIGNATURES = {
     "xp_last_error": (C.c_char_p, []),
     "xp_gemm": (i32, [C.POINTER(XpGemmDesc), vp]),
     "xp_gemm_auto_split": (i32, [C.POINTER(XpGemmDesc)]),
+    "xp_gemm_auto_split_slack": (i32, [C.POINTER(XpGemmDesc)]),
     "xp_set_cu_budget": (i32, [i32]),
     "xp_get_cu_budget": (i32, []),
     "xp_gemm_colsum_rows": (i64, [C.POINTER(XpGemmDesc)]),

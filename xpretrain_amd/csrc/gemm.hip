@@ -792,18 +792,26 @@ extern "C" int xp_set_cu_budget(int32_t cus) {
 }
 extern "C" int32_t xp_get_cu_budget(void) { return g_cu_budget; }
 
-extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) {
+// Split-K launches (the weight gradients) do not fill the chip: they run on the weight-gradient stream BESIDE the dX chain, which takes
+// whatever CUs they leave, and every split costs an fp32 slab written and read again -- at a fill of 256 (splits 7 / 9 / 27 for the
+// 36- / 27- / 9-tile outputs of ViT-B) the slabs of one layer are 260 MB each way, 6.2 GB per step, more than the optimizer moves.
+//   XP_SPLITK_FILL        176 CUs: the general answer (xp_gemm_auto_split): 4 / 6 / 19
+//   XP_SPLITK_FILL_SLACK  112 CUs: launches nothing waits for soon (xp_gemm_auto_split_slack: fc2, fc1, out_proj of a layer): 3 / - / 12
+// Whole step, interleaved: fill 256 -> 176 for all four: 15.55 -> 15.14 ms (208: 15.35, 144: 15.31, 128: 15.29;
+// profiles/r05s_in_step_ab_splitk_fill.txt); per-GEMM search around it (profiles/r05x_in_step_ab_splitk_per_gemm.txt): the q/k/v
+// gradient -- the last of the layer, the one the join waits for -- has a sharp optimum at 6 (4: +0.27 ms, 9: +0.24), fc1 / fc2 want 3
+// (4: +0.10, 5: +0.20), out_proj is flat between 12 and 19 (27: +0.08): 4/6/19 -> 3/6/12 is another -0.16 ms.
+constexpr int64_t XP_SPLITK_FILL = 176, XP_SPLITK_FILL_SLACK = 112;
+static int32_t auto_split_fill(const XpGemmDesc* d, int64_t fill);
+extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) { return auto_split_fill(d, XP_SPLITK_FILL); }
+extern "C" int32_t xp_gemm_auto_split_slack(const XpGemmDesc* d) { return auto_split_fill(d, XP_SPLITK_FILL_SLACK); }
+
+static int32_t auto_split_fill(const XpGemmDesc* d, int64_t fill) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 1;
   const int esz = d->in_dtype == XP_BF16 ? 2 : 4;
   const int64_t ke = BKB / esz;
   const int64_t t256 = cdiv(d->M, 256) * cdiv(d->N, 256);
-  // Split-K launches (the weight gradients) fill at most XP_SPLITK_FILL CUs, not the chip: they run on the weight-gradient stream
-  // BESIDE the dX chain, which takes whatever CUs they leave, and every split costs an fp32 slab written and read again -- at a
-  // fill of 256 (splits 7 / 9 / 27) the slabs of one layer are 260 MB each way, 6.2 GB per step, more than the optimizer moves;
-  // at 176 (splits 4 / 6 / 19) they are 150 MB and every workgroup runs a 1.6x longer k loop per prologue / epilogue.
-  // Whole step, interleaved (profiles/r05s_in_step_ab_splitk_fill.txt): 15.55 -> 15.14 ms (fill 208: 15.35, 144: 15.31, 128: 15.29).
-  constexpr int64_t XP_SPLITK_FILL = 176;
-  const int64_t cus = g_cu_budget < XP_SPLITK_FILL ? g_cu_budget : XP_SPLITK_FILL;
+  const int64_t cus = g_cu_budget < fill ? g_cu_budget : fill;
   int64_t s0 = cus / t256 < d->K / 512 ? cus / t256 : d->K / 512;
   const int s256 = valid_split(d->K, s0, 64);
   if (xp_gemm256_wanted(d, s256)) return s256;

@@ -29,11 +29,12 @@ XpGemmDesc gemm_desc(const void* A, const void* B, void* C, int64_t M, int64_t N
 }
 
 // dW[n_out, n_in] = dY[rows, n_out]^T . X[rows, n_in], fp32: both operands k-strided, split-K chosen by the library
+// slack: nothing waits for this launch soon (xp_gemm_auto_split_slack: fewer, longer slabs)
 int wgrad(const void* dy, const void* x, float* dw, int64_t rows, int64_t n_out, int64_t n_in, int dtype, float* slabs,
-          size_t slab_bytes, void* st) {
+          size_t slab_bytes, void* st, bool slack) {
   XpGemmDesc d = gemm_desc(dy, x, dw, n_out, n_in, rows, dtype);
   d.a_kstrided = d.b_kstrided = 1; d.lda = n_out; d.ldb = n_in; d.out_dtype = XP_F32;
-  const int split = xp_gemm_auto_split(&d);
+  const int split = slack ? xp_gemm_auto_split_slack(&d) : xp_gemm_auto_split(&d);
   if (split <= 1) return xp_gemm(&d, st);
   XP_REQUIRE(slab_bytes >= (size_t)split * n_out * n_in * sizeof(float), "xp_encoder_layer_bwd: split-K slab space too small");
   d.C = slabs; d.split_k = split;
@@ -45,7 +46,7 @@ int wgrad(const void* dy, const void* x, float* dw, int64_t rows, int64_t n_out,
 size_t wgrad_slab_bytes(int64_t rows, int64_t n_out, int64_t n_in, int dtype) {
   XpGemmDesc d = gemm_desc(nullptr, nullptr, nullptr, n_out, n_in, rows, dtype);
   d.a_kstrided = d.b_kstrided = 1; d.lda = n_out; d.ldb = n_in; d.out_dtype = XP_F32;
-  const int split = xp_gemm_auto_split(&d);
+  const int a = xp_gemm_auto_split(&d), b = xp_gemm_auto_split_slack(&d), split = a > b ? a : b;
   return split <= 1 ? 0 : (size_t)split * n_out * n_in * sizeof(float);
 }
 
@@ -260,12 +261,12 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
       df.add(cs_pre, a->db1, Dff, (int)r, (int)Dff);
     }
   }
-  if (a->dw2 && (rc = wgrad(a->dx3, a->act, a->dw2, rows, D, Dff, dt, slabs, p.slabs, wst))) return rc;
+  if (a->dw2 && (rc = wgrad(a->dx3, a->act, a->dw2, rows, D, Dff, dt, slabs, p.slabs, wst, true))) return rc;
   if ((rc = mark(1))) return rc;                                              // dpre is ready for dW1
   g = gemm_desc(dpre, a->W1, dh2, rows, D, Dff, dt);                          // dh2 = dpre . W1
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
-  if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, wst))) return rc;
+  if (a->dw1 && (rc = wgrad(dpre, a->h2, a->dw1, rows, Dff, D, dt, slabs, p.slabs, wst, true))) return rc;
   // dx2 = dx3 + LN2'(dh2); partial rows [dgamma | dbeta | colsum(dx2) | colsum(dx3)] -- out_proj's and fc2's bias gradients
   if ((rc = xp_layernorm_bwd_partials_side(dh2, D, a->x2, D, a->ln2_w, a->mean2, a->rstd2, a->dx3, D, dx2, D, 2, rows, D, dt,
                                            a->side_x2, a->side_S, a->side_M, a->side_M, ln2_part, p.ln2, st))) return rc;
@@ -278,14 +279,14 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
   g = gemm_desc(dx2, a->Wo, dattn, rows, D, D, dt);                           // dattn = dx2 . Wo
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
-  if (a->dwo && (rc = wgrad(dx2, a->attn_o, a->dwo, rows, D, D, dt, slabs, p.slabs, wst))) return rc;
+  if (a->dwo && (rc = wgrad(dx2, a->attn_o, a->dwo, rows, D, D, dt, slabs, p.slabs, wst, true))) return rc;
   if ((rc = xp_attn_bwd2(a->qkv, 3 * D, a->attn_o, dattn, D, a->stats, a->pad_mask, dqkv, d.q_scale, d.attn_mode, d.B, d.heads,
                          d.S, d.M, d.N, d.L, dt, attn_ws, p.attn, (a->dbqkv && p.cs_qkv_fused) ? cs_qkv : nullptr, st))) return rc;
   if ((rc = mark(3))) return rc;                                              // dqkv is ready for dWqkv
   g = gemm_desc(dqkv, a->Wqkv, dh1, rows, D, 3 * D, dt);                      // dh1 = dqkv . Wqkv
   g.b_kstrided = 1; g.ldb = D;
   if ((rc = xp_gemm(&g, st))) return rc;
-  if (a->dwqkv && (rc = wgrad(dqkv, a->h1, a->dwqkv, rows, 3 * D, D, dt, slabs, p.slabs, wst))) return rc;
+  if (a->dwqkv && (rc = wgrad(dqkv, a->h1, a->dwqkv, rows, 3 * D, D, dt, slabs, p.slabs, wst, false))) return rc;
   if (a->dbqkv) {
     if (!p.cs_qkv_fused && (rc = xp_colsum_partials(dqkv, rows, 3 * D, 3 * D, dt, cs_qkv, p.cs_qkv, st))) return rc;
     df.add(cs_qkv, a->dbqkv, 3 * D, (int)p.cs_qkv_rows, (int)(3 * D));

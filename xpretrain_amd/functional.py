@@ -145,18 +145,19 @@ WEIGHTS = WeightCache()
 _SPLITS = {}
 
 
-def _split_for(n_out: int, n_in: int, rows: int, dtype: torch.dtype, a_remap) -> int:
-    """split-K factor for the weight-gradient GEMMs (kernel-family aware, decided by the library; memoised)."""
-    key = (n_out, n_in, rows, dtype, a_remap)
+def _split_for(n_out: int, n_in: int, rows: int, dtype: torch.dtype, a_remap, slack: bool = False) -> int:
+    """split-K factor for the weight-gradient GEMMs (kernel-family aware, decided by the library; memoised).  ``slack``: a launch
+    nothing waits for soon (the first three dW GEMMs of a layer's backward, as csrc/layer.hip issues them): fewer, longer slabs."""
+    key = (n_out, n_in, rows, dtype, a_remap, slack)
     s = _SPLITS.get(key)
     if s is None:
-        s = _SPLITS[key] = H.gemm_auto_split(n_out, n_in, rows, dtype, lda=n_out, ldb=n_in, a_remap=a_remap)
+        s = _SPLITS[key] = H.gemm_auto_split(n_out, n_in, rows, dtype, lda=n_out, ldb=n_in, a_remap=a_remap, slack=slack)
     return s
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, a_remap=(0, 0, 0)) -> torch.Tensor:
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, rows: int, n_out: int, n_in: int, a_remap=(0, 0, 0), slack: bool = False) -> torch.Tensor:
     """dW[n_out, n_in] = dY[rows, n_out]^T . X[rows, n_in] in fp32 (both operands read k-strided, split-K)."""
-    split = _split_for(n_out, n_in, rows, dy.dtype, tuple(a_remap))
+    split = _split_for(n_out, n_in, rows, dy.dtype, tuple(a_remap), slack)
     dw = torch.empty((n_out, n_in), dtype=torch.float32, device=dy.device)
     if split == 1:
         H.gemm(dy, x, n_out, n_in, rows, a_kstrided=True, b_kstrided=True, lda=n_out, ldb=n_in, out=dw,
@@ -541,16 +542,16 @@ class EncoderLayerFn(torch.autograd.Function):
                                   colsum_name="db1")
         else:
             dpre, db1 = H.gemm(dx3, W2, rows, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=pre), None
-        dw2 = _wgrad(dx3, act, rows, D, Dff) if need[15] else None
+        dw2 = _wgrad(dx3, act, rows, D, Dff, slack=True) if need[15] else None
         dh2 = H.gemm(dpre, W1, rows, D, Dff, b_kstrided=True)
-        dw1 = _wgrad(dpre, h2, rows, Dff, D) if need[13] else None
+        dw1 = _wgrad(dpre, h2, rows, Dff, D, slack=True) if need[13] else None
         # out_proj's bias gradient = column sums of dx2, fc2's = column sums of dx3: both accumulated by the LayerNorm backward
         # that reads dx3 and writes dx2
         dx2, dln2_w, dln2_b, dbo, db2 = H.layernorm_bwd(dh2, x2, ln2_w, mean2, rstd2, rows, D, dres=dx3, defer=defer,
                                                         dx_colsum=True, dres_colsum=True, name="ln2", x_side=side_x2, side=ctx.lns)
         # ---- attention: x2 = x + out_proj(attn(qkv(LN1(x))))
         dattn = H.gemm(dx2, Wo, rows, D, D, b_kstrided=True)
-        dwo = _wgrad(dx2, attn_o, rows, D, D) if need[9] else None
+        dwo = _wgrad(dx2, attn_o, rows, D, D, slack=True) if need[9] else None
         want_bqkv = need[4] or need[6] or need[8]
         if want_bqkv:       # the q/k/v bias gradients (column sums of dqkv) come out of the attention backward kernels
             dqkv, dbqkv = H.attn_bwd(qkv, attn_o, dattn, stats, B, S, heads, size=size, pad_mask=pad_mask, q_scale=q_scale,

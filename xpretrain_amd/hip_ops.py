@@ -132,8 +132,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
 
 
 def gemm_auto_split(M: int, N: int, K: int, dtype: torch.dtype, *, a_kstrided=True, b_kstrided=True, lda=None,
-                    ldb=None, a_remap=(0, 0, 0)) -> int:
-    """Split-K factor for a weight-gradient GEMM (see include/xpretrain_hip.h::xp_gemm_auto_split)."""
+                    ldb=None, a_remap=(0, 0, 0), slack=False) -> int:
+    """Split-K factor for a weight-gradient GEMM (see include/xpretrain_hip.h::xp_gemm_auto_split / _slack)."""
     d = L.XpGemmDesc()
     d.M, d.N, d.K = M, N, K
     d.lda = lda if lda is not None else (M if a_kstrided else K)
@@ -142,7 +142,7 @@ def gemm_auto_split(M: int, N: int, K: int, dtype: torch.dtype, *, a_kstrided=Tr
     d.a_kstrided, d.b_kstrided = int(a_kstrided), int(b_kstrided)
     d.in_dtype, d.out_dtype = _DT[dtype], _DT[torch.float32]
     d.a_grp, d.a_grp_stride, d.a_off = a_remap
-    return int(L.lib().xp_gemm_auto_split(C.byref(d)))
+    return int((L.lib().xp_gemm_auto_split_slack if slack else L.lib().xp_gemm_auto_split)(C.byref(d)))
 
 
 def splitk_reduce(slabs: torch.Tensor, out: torch.Tensor, accumulate=False, splits=None) -> torch.Tensor:
