@@ -5,7 +5,7 @@ of tools/pmc_gemm256.sh -- next to a calibration kernel of exactly known traffic
 
   NT  fc1 forward   [18848 x 768] x [3072 x 768]^T  +bias +quick_gelu, two bf16 outputs   (gemm256_kernel<false,false>)
   NS  dpre = dx3.W2 [18848 x 768] x [768 x 3072]    *quick_gelu'(pre), fused column sums  (gemm256_kernel<false,true>)
-  SS  dW1 = dpre^T.h2, split-K 7 into fp32 slabs                                         (gemm256_kernel<true,true>)
+  SS  dW1 = dpre^T.h2, split-K 3 into fp32 slabs                                         (gemm256_kernel<true,true>)
 """
 import sys
 
@@ -34,6 +34,6 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     d = H.DeferredReduce(torch.device(dev))
     H.gemm(dx3, W2, M, Dff, D, b_kstrided=True, epilogue=L.EPI_GELU_BWD, resid=aux, out=dpre, colsum_defer=d)
     d.flush()
-    _wgrad(dpre, A, M, Dff, D)
+    _wgrad(dpre, A, M, Dff, D, slack=True)        # (as the layer backward issues it: xp_gemm_auto_split_slack)
 torch.cuda.synchronize()
 print("done")
