@@ -108,4 +108,6 @@ class PrefetchLoader(object):
         return batch
 
     def __getattr__(self, name):
+        if name in ("loader", "stream", "batch"):          # (not set yet: e.g. while unpickling -- do not recurse)
+            raise AttributeError(name)
         return self.loader.__getattribute__(name)
