@@ -266,9 +266,10 @@ def self_launch(n):
 
 
 def parse_rccl_log(text):
-    """channels / algorithm / protocol from RCCL's NCCL_DEBUG=INFO (INIT,TUNING) lines; the raw lines it matched are kept"""
+    """channels, the environment settings RCCL says it honoured, and (when the TUNING subsystem was on) algorithm / protocol per
+    message size, from RCCL's NCCL_DEBUG=INFO lines; the raw lines it matched are kept"""
     import re
-    out = {"coll_channels": None, "ring_channel_lines": 0, "tuning": [], "raw": []}
+    out = {"coll_channels": None, "ring_channel_lines": 0, "env_honoured": {}, "tuning": [], "raw": []}
     algos = {0: "Tree", 1: "Ring", 2: "CollnetDirect", 3: "CollnetChain", 4: "NVLS", 5: "NVLSTree"}
     protos = {0: "LL", 1: "LL128", 2: "Simple"}
     seen = set()
@@ -278,6 +279,9 @@ def parse_rccl_log(text):
             out["coll_channels"] = int(m.group(1)); out["raw"].append(line.strip()[-160:])
         if re.search(r"NCCL INFO Channel \d+/\d+\s*:", line):
             out["ring_channel_lines"] += 1
+        m = re.search(r"((?:NCCL|RCCL)_\w+) set by environment to (\S+?)\.?$", line.strip())
+        if m:
+            out["env_honoured"][m.group(1)] = m.group(2)
         m = re.search(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", line)
         if m:
             key = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)))
@@ -288,7 +292,7 @@ def parse_rccl_log(text):
 
 
 def dp_diagnostics(step, reducer, sync, dev, rank, W, n_seen, cu_budget, steps=3):
-    """Per-rank facts of a data-parallel run, gathered on rank 0 (VERDICT r4 #9): the ranks this rank saw, what RCCL chose, the
+    """Per-rank facts of a data-parallel run, gathered on rank 0: the ranks this rank saw, what RCCL chose, the
     gradient buckets, and the EXPOSED tail of the gradient exchange -- main-stream time inside reducer.synchronize() (everything the
     backward did not hide), HIP events, mean of `steps` extra steps after the timed region."""
     import glob
@@ -344,7 +348,9 @@ def main():
         # parses after the timed region: the first multi-GPU run then shows whether the defaults above were honoured
         if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN"):      # (the image exports NCCL_DEBUG=VERSION)
             os.environ["NCCL_DEBUG"] = "INFO"
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+        # INIT + ENV only: both print while the communicator is built, nothing per collective (TUNING would write a line per
+        # enqueued collective -- inside the timed steps)
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,ENV")
         os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "xp_bench_rccl.%h.%p.log"))
     local_rank = D.init_from_env()
     W, rank = D.world_size(), D.rank()

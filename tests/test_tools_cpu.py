@@ -125,9 +125,12 @@ def test_bench_parses_what_rccl_reports_it_chose():
         "node:11:22 [3] NCCL INFO 32 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer",
         "node:11:22 [3] NCCL INFO AllReduce: 67108864 Bytes -> Algo 1 proto 2 time 512.3",
         "node:11:22 [3] NCCL INFO AllReduce: 67108864 Bytes -> Algo 1 proto 2 time 512.3",
-        "node:11:22 [3] NCCL INFO AllGather: 16384 Bytes -> Algo 1 proto 0 time 12.3"])
+        "node:11:22 [3] NCCL INFO AllGather: 16384 Bytes -> Algo 1 proto 0 time 12.3",
+        "node:11:22 [3] NCCL INFO NCCL_MAX_NCHANNELS set by environment to 32.",
+        "node:11:22 [3] NCCL INFO NCCL_ALGO set by environment to Ring"])
     got = bench.parse_rccl_log(log)
     assert got["coll_channels"] == 32 and got["ring_channel_lines"] == 2
     assert got["tuning"] == [{"op": "AllReduce", "bytes": 67108864, "algo": "Ring", "proto": "Simple"},
                              {"op": "AllGather", "bytes": 16384, "algo": "Ring", "proto": "LL"}]
+    assert got["env_honoured"] == {"NCCL_MAX_NCHANNELS": "32", "NCCL_ALGO": "Ring"}
     assert bench.parse_rccl_log("")["coll_channels"] is None
