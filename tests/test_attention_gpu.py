@@ -125,3 +125,32 @@ def test_backward_emits_the_qkv_bias_column_sums(geom):
     assert torch.equal(dqkv, ref)
     want = dqkv.double().sum(0)
     assert report(f"attn bwd fused colsum {geom}", cs, want, 1e-5, scale_floor=1e-3) <= 1e-5
+
+
+@pytest.mark.parametrize("geom,B,Hh", [((4, 12, 196), 2, 3), ((4, 2, 49), 2, 2), ((1, 3, 5), 2, 1), ((16, 3, 192), 1, 2), ((4, 7, 204), 1, 2),
+                                       ((3, 40, 100), 3, 5)])
+def test_fused_backward_against_the_two_kernel_path(geom, B, Hh, monkeypatch):
+    """attn_bwd5_kernel (one launch: dQ, dK, dV, the bias column sums; problems handed out by a device counter) against the dQ / dKV
+    kernel pair on identical inputs (XPRETRAIN_DEBUG=attn_bwd_split): same operands, same rounding points, different summation order
+    -- within 1e-2 of the tensor scale on bf16 outputs (one bf16 ulp is 4e-3); the last case has more problems than CUs (every
+    workgroup pulls several from the counter) and a 13-tile-free shape; run twice: the counter decides only WHO computes a problem."""
+    from xpretrain_amd import hip_ops as H
+    M, N, Lp = geom
+    S = M + N * Lp
+    torch.manual_seed(3)
+    qkv = (torch.randn(B * S, 3 * Hh * 64, device="cuda") * 0.7).to(torch.bfloat16)
+    out, stats = H.attn_fwd(qkv, B, S, Hh, size=geom)
+    dout = torch.randn_like(out)
+    d = H.DeferredReduce(qkv.device)
+    got, cs = H.attn_bwd(qkv, out, dout, stats, B, S, Hh, size=geom, q_scale=0.125, colsum_defer=d)
+    d.flush()
+    again = H.attn_bwd(qkv, out, dout, stats, B, S, Hh, size=geom, q_scale=0.125)
+    assert torch.equal(got, again)
+    monkeypatch.setenv("XPRETRAIN_DEBUG", "attn_bwd_split")
+    want = H.attn_bwd(qkv, out, dout, stats, B, S, Hh, size=geom, q_scale=0.125)
+    monkeypatch.delenv("XPRETRAIN_DEBUG")
+    assert torch.isfinite(got.float()).all()
+    for j, name in enumerate("qkv"):
+        a, b = [t.view(B * S, 3, Hh * 64)[:, j] for t in (got, want)]
+        assert report(f"attn bwd fused vs split {geom} d{name}", a, b, 1e-2) <= 1e-2
+    assert report(f"attn bwd fused colsum vs stored {geom}", cs, got.double().sum(0), 1e-5, scale_floor=1e-3) <= 1e-5

@@ -30,6 +30,39 @@ kernel:
 """     # compiler-emitted read (no ASMSTART marker): hipcc tracks its own waits, not the lint's business
 
 
+# hipcc rotates loops: the block with the wait is laid out BEFORE the reads and reached by a branch; what follows the loop in the
+# file (here a use of v9 for something else) is not on any path from the reads without the wait
+ROTATED = """
+kernel:
+\ts_branch .LBB0_2
+.LBB0_1:
+\ts_waitcnt lgkmcnt(0)
+\tv_mfma_f32_16x16x32_bf16 v[2:5], v[8:11], v[8:11], v[2:5]
+\ts_cbranch_scc1 .LBB0_3
+.LBB0_2:
+\t;;#ASMSTART
+\tds_read_b64_tr_b16 v[8:9], v7 offset:0
+\t;;#ASMEND
+\ts_branch .LBB0_1
+.LBB0_3:
+\tv_mov_b32_e32 v9, v1
+\ts_endpgm
+"""
+# one arm of a conditional branch reaches a use without the wait
+BRANCH_BAD = """
+kernel:
+\t;;#ASMSTART
+\tds_read_b64_tr_b16 v[10:11], v5 offset:0
+\t;;#ASMEND
+\ts_cbranch_scc1 .LBB0_2
+\tv_add_f32 v1, v10, v2
+.LBB0_2:
+\ts_waitcnt lgkmcnt(0)
+\tv_add_f32 v1, v10, v2
+\ts_endpgm
+"""
+
+
 def _run(tmp_path, text):
     f = tmp_path / "k.s"
     f.write_text(text)
@@ -44,6 +77,12 @@ def test_lint_accepts_waited_reads(tmp_path):
 def test_lint_flags_use_before_wait(tmp_path, capsys):
     assert _run(tmp_path, BAD) == 1
     assert "before s_waitcnt lgkmcnt(0)" in capsys.readouterr().out
+
+
+def test_lint_follows_the_control_flow(tmp_path, capsys):
+    assert _run(tmp_path, ROTATED) == 0
+    assert _run(tmp_path, BRANCH_BAD) == 1
+    assert ":7:" in capsys.readouterr().out
 
 
 def test_register_parser():

@@ -12,7 +12,7 @@ built with XP_NO_PK_F32 (csrc/common.h).
 The asm `ds_read_b64_tr_b16` is invisible to hipcc's waitcnt bookkeeping, so the source places an explicit
 `s_waitcnt lgkmcnt(0)` before the first use of its result.  This script checks the GENERATED code: between every
 `ds_read_b64_tr_b16 v[a:b], ...` that came from inline asm (marked by the `;;#ASMSTART` / `;;#ASMEND` pair hipcc emits) and
-the next `s_waitcnt` that waits lgkmcnt(0), no instruction may mention v[a..b] as an operand.  Usage:
+the next `s_waitcnt` that waits lgkmcnt(0) ON EVERY CONTROL-FLOW PATH, no instruction may mention v[a..b] as an operand.  Usage:
     check_isa.py file.s [...] [--asm-reads file.s [...]]      exit status 1 on a violation
 """
 import re
@@ -48,36 +48,59 @@ def check_pk(path):
 
 
 def check(path):
-    bad = 0
-    pending = {}          # register -> line number of the asm read that wrote it
+    """lint (2): from every inline-asm transpose read, follow the control flow (fall-through, s_branch, both arms of s_cbranch_*) until
+    an `s_waitcnt` with lgkmcnt(0) or `s_endpgm`; no instruction on the way may mention the read's destination registers.  (hipcc
+    rotates loops: the block holding the wait is often laid out BEFORE the reads and reached by a branch -- a linear scan would flag
+    whatever happens to follow the loop in the file.)"""
+    insts, labels = [], {}          # (line number, text, is_asm_read)
     in_asm = False
     for ln, raw in enumerate(open(path), 1):
-        line = raw.split(";")[0].strip() if not raw.lstrip().startswith(";;#") else raw.strip()
-        if raw.lstrip().startswith(";;#ASMSTART"):
+        st = raw.lstrip()
+        if st.startswith(";;#ASMSTART"):
             in_asm = True
             continue
-        if raw.lstrip().startswith(";;#ASMEND"):
+        if st.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        if not line or line.endswith(":") or line.startswith("."):
-            continue          # labels: the scan is linear in layout order (the kernels read and wait in one block or fall through)
-        if in_asm and line.startswith("ds_read_b64_tr_b16"):
-            dst = line.split(",")[0]
-            for r in regs_of(dst):
-                pending[r] = ln
+        line = raw.split(";")[0].strip()
+        if not line:
             continue
-        if line.startswith("s_waitcnt") and "lgkmcnt(0)" in line:
-            pending.clear()
+        if line.endswith(":"):
+            labels[line[:-1]] = len(insts)
             continue
-        if line.startswith("s_endpgm"):
-            pending.clear()
+        if line.startswith("."):
             continue
-        if pending:
-            used = regs_of(line) & set(pending)
-            if used:
-                print(f"{path}:{ln}: `{line}` touches v{sorted(used)} written by the asm transpose read at line "
-                      f"{pending[min(used)]} before s_waitcnt lgkmcnt(0)")
-                bad += 1
+        insts.append((ln, line, in_asm and line.startswith("ds_read_b64_tr_b16")))
+    bad = 0
+    reported = set()
+    for start, (ln0, line0, is_read) in enumerate(insts):
+        if not is_read:
+            continue
+        dst = regs_of(line0.split(",")[0])
+        stack, seen = [start + 1], set()
+        while stack:
+            i = stack.pop()
+            while i < len(insts) and i not in seen:
+                seen.add(i)
+                ln, line, rd = insts[i]
+                if line.startswith("s_endpgm") or (line.startswith("s_waitcnt") and "lgkmcnt(0)" in line):
+                    break
+                if rd:                      # another asm read: its own walk covers its registers; this one's stay pending
+                    i += 1
+                    continue
+                used = regs_of(line) & dst
+                if used and (ln, ln0) not in reported:
+                    reported.add((ln, ln0))
+                    print(f"{path}:{ln}: `{line}` touches v{sorted(used)} written by the asm transpose read at line {ln0} "
+                          "before s_waitcnt lgkmcnt(0)")
+                    bad += 1
+                if line.startswith("s_branch") or line.startswith("s_cbranch"):
+                    tgt = line.split()[-1]
+                    if tgt in labels:
+                        stack.append(labels[tgt])
+                    if line.startswith("s_branch"):
+                        break
+                i += 1
     return bad
 
 

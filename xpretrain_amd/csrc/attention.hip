@@ -42,6 +42,7 @@ struct AP {
   int nq, nprob;                        // forward: query blocks per problem, problems
   float q_scale;
   float* ws0; float* ws1; float* ws2;   // fwd: partials | bwd: delta, dq partials, dkv partials
+  int dbg;
   float* cs; int cs_main;               // bwd, optional: column-sum partial rows of dqkv [cs_main + B*M][3*H*64] (see xp_attn_bwd2)
 };
 
@@ -1093,6 +1094,461 @@ __global__ __launch_bounds__(256) void attn_bwd_proxy_reduce_kernel(AP p) {
   }
 }
 
+// ============================================================================================ backward, fused (round 6)
+// The two kernels above are issue-bound, not HBM-bound (same time with their operands in the Infinity Cache): per SIMD, 3.5 one-tile
+// waves each read every staged fragment for themselves, the softmax arithmetic is 6.5 VALU per score, and every problem is staged
+// twice per kernel (two 112-row blocks) -- 434 KB through the CU per problem for 205 KB of operands and results.  attn_bwd5_kernel is
+// ONE launch for dQ, dK and dV of the proxy problems that fit one LDS group (R <= 208, M <= 16, no padding mask -- the shapes of
+// attn_fwd3_kernel):
+//   * one persistent 8-wave workgroup per CU, problems handed out by a device counter (late workgroups -- the CUs a weight-gradient
+//     GEMM of the other stream held at launch -- simply take fewer), every operand staged ONCE per problem by LDS-DMA:
+//     X = {K, V} image, Y = {Q, dO} image, 26 KiB each;
+//   * phase A (own = 2 query tiles per wave, S^T orientation, reads X) -> dQ; phase B (own = 2 key tiles per wave, reads Y, own K / V
+//     fragments taken from X) -> dK, dV.  A true single pass (5 matmuls, one exp) needs the cross-wave dQ sum staged through LDS
+//     beside a prefetched second problem: 163.7 of the 160 KiB; what the recompute costs here is MFMA time the HBM
+//     stream hides, what it saves is every barrier inside a problem.  X of the NEXT problem lands during phase B, Y during phase A:
+//     two barriers per problem, both of them the points where a DMA must have landed anyway;
+//   * both tiles of a wave share every fragment read (half the LDS traffic per score of the one-tile kernels);
+//   * softmax arithmetic 3.5-4 VALU per score: the row constants ride in as the MFMA's C operand (S starts from -(m + log l), dP from
+//     -delta), P = exp2(S * log2 e), dS = P * dP;
+//   * delta = rowsum(dO * O) stays in the workgroup (LDS) -- no global publication, no ordering between two launches;
+//   * the q/k/v bias column sums ride on the two barriers a problem has anyway.
+// Deterministic: fixed summation order everywhere, the counter only decides WHICH workgroup computes a problem.
+constexpr int B5W = 8, B5THR = B5W * 64;
+constexpr int B5_ROWS = FG + 16;                               // 13 staged tiles + one pad tile of zeros: every step is two sub-tiles
+constexpr int B5_IMG = B5_ROWS * 128;                          // one operand image
+constexpr int B5_OFF_STATS = 4 * B5_IMG;                       // c[B5_ROWS] = -(m + log l), nd[B5_ROWS] = -delta
+constexpr int B5_OFF_RED = B5_OFF_STATS + 2 * B5_ROWS * 4;     // column-sum partials [3][B5W][DH]
+constexpr int B5_OFF_NEXT = B5_OFF_RED + 3 * B5W * DH * 4;
+constexpr int B5_LDS = B5_OFF_NEXT + 16;
+
+// rows [0, FG) of one row-major operand (the 64 elements of a (token, head) slice; rows >= R read as zero) -> linear swizzled LDS
+// image by LDS-DMA, one wave instruction = 8 rows x 128 B.  The per-lane part of the source offset does not depend on the problem
+// (vrow: byte offset of the lane's row inside a 64-row block + its swizzled 16-byte chunk); the frame and the 64-row block ride in
+// the scalar offset, so a problem costs the loader no vector registers beyond the proxy rows of block 0 (voff0).
+__device__ __forceinline__ void b5_stage(char* img, __amdgpu_buffer_rsrc_t rs, unsigned ld_bytes, unsigned soff, unsigned vrow,
+                                         unsigned voff0, int R, unsigned frame_off, int lane, int wave, int dbg = 0, int M_ = 0) {
+  typedef __attribute__((address_space(3))) char lds_c;
+  constexpr int NPASS = FG / 8;
+#pragma unroll
+  for (int j = 0; j < (NPASS + B5W - 1) / B5W; ++j) {
+    const int pass = j * B5W + wave;
+    if (pass < NPASS) {
+      const int row = pass * 8 + (lane >> 3);
+      unsigned v = row < R ? (j == 0 ? voff0 : vrow) : 0xFFFFFF00u;
+      unsigned so = j == 0 ? soff : soff + frame_off + (unsigned)(j * 64) * ld_bytes;
+      if (dbg & 2) {
+        const int c = (lane & 7) ^ swz128(row);
+        const int tok = row >= M_ ? row + (int)(frame_off / ld_bytes) : row;
+        v = row < R ? (unsigned)tok * ld_bytes + c * 16 : 0xFFFFFF00u; so = soff;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(img + pass * 1024), 16, v, so, 0, 0);
+    }
+  }
+}
+struct B5Lane { unsigned vq, vo, v0q, v0o; };                 // per-lane source offsets for pitch ldqkv / ldo (block >= 1 / block 0)
+__device__ __forceinline__ void b5_lane_offsets(B5Lane& L, const AP& p, int n, int lane, int wave) {
+  const int row = wave * 8 + (lane >> 3);                       // the lane's row inside a 64-row block
+  const unsigned c16 = (unsigned)(((lane & 7) ^ swz128(row)) * 16);
+  L.vq = (unsigned)row * (unsigned)(p.ldqkv * 2) + c16;
+  L.vo = (unsigned)row * (unsigned)(p.ldo * 2) + c16;
+  const unsigned tok0 = (unsigned)tok_of(p, n, row);            // block 0 holds the proxy rows: token index by the general rule
+  L.v0q = tok0 * (unsigned)(p.ldqkv * 2) + c16;
+  L.v0o = tok0 * (unsigned)(p.ldo * 2) + c16;
+}
+__device__ __forceinline__ void b5_stage_kv(char* X, const AP& p, const Prob& pr, int lane, int wave) {
+  const bf16_t* kbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + (int64_t)p.H * DH + pr.h * DH;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (unsigned)((int64_t)p.S * p.ldqkv * 2 - ((int64_t)p.H * DH + pr.h * DH) * 2), 0x00020000);
+  B5Lane L; b5_lane_offsets(L, p, pr.n, lane, wave);
+  const unsigned ld = (unsigned)(p.ldqkv * 2), fo = (unsigned)(pr.n * p.L) * ld;
+  b5_stage(X, rs, ld, 0, L.vq, L.v0q, p.R, fo, lane, wave, p.dbg, p.M);
+  b5_stage(X + B5_IMG, rs, ld, (unsigned)(p.H * DH * 2), L.vq, L.v0q, p.R, fo, lane, wave, p.dbg, p.M);
+}
+__device__ __forceinline__ void b5_stage_qdo(char* Y, const AP& p, const Prob& pr, int lane, int wave) {
+  const bf16_t* qbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
+  const bf16_t* dobase = p.dout + (int64_t)pr.b * p.S * p.ldo + pr.h * DH;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(qbase), 0, (unsigned)(((int64_t)p.S * p.ldqkv - pr.h * DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(dobase), 0, (unsigned)(((int64_t)p.S * p.ldo - pr.h * DH) * 2), 0x00020000);
+  B5Lane L; b5_lane_offsets(L, p, pr.n, lane, wave);
+  const unsigned ldq = (unsigned)(p.ldqkv * 2), ldo = (unsigned)(p.ldo * 2);
+  b5_stage(Y, rq, ldq, 0, L.vq, L.v0q, p.R, (unsigned)(pr.n * p.L) * ldq, lane, wave, p.dbg, p.M);
+  b5_stage(Y + B5_IMG, rdo, ldo, 0, L.vo, L.v0o, p.R, (unsigned)(pr.n * p.L) * ldo, lane, wave, p.dbg, p.M);
+}
+
+// the wave's own query rows (tiles wave, wave + 8; rows >= R: zeros) straight from global memory: Q, dO, O fragments and (m, log l)
+struct B5Own { bf16x8 q[2][2], d[2][2], o[2][2]; float m[2], lg[2]; };
+__device__ __forceinline__ void b5_load_own(B5Own& w, const AP& p, const Prob& pr, int wave, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const bf16_t* qbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(qbase), 0, (unsigned)(((int64_t)p.S * p.ldqkv - pr.h * DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.dout + (int64_t)pr.b * p.S * p.ldo + pr.h * DH), 0, (unsigned)(((int64_t)p.S * p.ldo - pr.h * DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.out + (int64_t)pr.b * p.S * p.ldo + pr.h * DH), 0, (unsigned)(((int64_t)p.S * p.ldo - pr.h * DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(
+      p.stats + ((int64_t)pr.b * p.H + pr.h) * p.S * 2, 0, (unsigned)(p.S * 8), 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rq_ = (wave + B5W * i) * 16 + i16;
+    const bool ok = rq_ < p.R;
+    const unsigned tok = (unsigned)tok_of(p, pr.n, ok ? rq_ : 0);
+    const unsigned oq = ok ? tok * (unsigned)(p.ldqkv * 2) + g * 16 : 0xFFFFFF00u;
+    const unsigned oo = ok ? tok * (unsigned)(p.ldo * 2) + g * 16 : 0xFFFFFF00u;
+    if (p.dbg & 1) {
+      const int64_t tk = (int64_t)pr.b * p.S + tok;
+      load_row_frag(w.q[i], p.qkv + tk * p.ldqkv + pr.h * DH, ok, g);
+      load_row_frag(w.d[i], p.dout + tk * p.ldo + pr.h * DH, ok, g);
+      load_row_frag(w.o[i], p.out + tk * p.ldo + pr.h * DH, ok, g);
+      const float* sp = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok) * 2;
+      w.m[i] = ok ? sp[0] : 0.f; w.lg[i] = ok ? sp[1] : 0.f;
+      continue;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      w.q[i][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, oq + kk * 64, 0, 0));
+      w.d[i][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdo, oo + kk * 64, 0, 0));
+      w.o[i][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, oo + kk * 64, 0, 0));
+    }
+    const unsigned os = ok ? tok * 8u : 0xFFFFFF00u;          // rows >= R: (0, 0).  (two dword loads: hipcc lowers the b64 builtin
+    w.m[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rst, os, 0, 0));          //  to ONE dword, splat)
+    w.lg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rst, os + 4, 0, 0));
+  }
+}
+
+struct B5TFrag { bf16x8 f[4]; };                             // transposed A fragments of a 32-row step for the four d tiles
+__device__ __forceinline__ void b5_tfrag(B5TFrag& t, const char* tile, int lane) {      // asm reads: wait lgkmcnt(0) before use
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) t.f[dt] = frag_cols_async(tile, dt, 0, lane);
+}
+
+// phase A step: two sixteen-key sub-tiles at LDS row t0 * 16 against the wave's two query tiles (S^T orientation: the lane owns
+// query column i16 of each tile; rows 4g + r are keys).  tail: the step reaches past key R (those P are forced to zero: their K rows
+// are zero-filled, but P * 0 must not see an overflowed P).  corner: the wave's first tile holds the proxy query rows and this is a
+// frame n != 0 -- proxy x proxy scores are counted in frame 0 only.
+__device__ __forceinline__ void b5_dq_step(f32x4 (&dq)[2][4], const AP& p, const char* gK, const char* gV, const B5Own& w,
+                                           const f32x4 (&c4)[2], const f32x4 (&nd4)[2], int t0, bool corner, bool tail, int lane) {
+  const int g = lane >> 4, i16 = lane & 15;
+  f32x4 s[2][2], dp[2][2];
+  {
+    bf16x8 kf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) kf[t][kk] = frag_rows(gK, t0 + t, kk, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) s[i][t] = mma16(kf[t][1], w.q[i][1], mma16(kf[t][0], w.q[i][0], c4[i]));
+  }
+  {
+    bf16x8 vf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) vf[t][kk] = frag_rows(gV, t0 + t, kk, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dp[i][t] = mma16(vf[t][1], w.d[i][1], mma16(vf[t][0], w.d[i][0], nd4[i]));
+  }
+  B5TFrag kt;
+  __builtin_amdgcn_sched_barrier(0);
+  b5_tfrag(kt, gK + t0 * 16 * 128, lane);                  // row shift by a multiple of 16 keeps the swizzle phase
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[i][t][r] = __builtin_amdgcn_exp2f(s[i][t][r] * LOG2E);
+  if (tail) {
+    const int klim = p.R - t0 * 16 - 4 * g;                // the lane's key rows are t0*16 + 16t + 4g + r: valid iff 16t + r < klim
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[i][t][r] = (16 * t + r < klim) ? s[i][t][r] : 0.f;
+  }
+  if (corner && t0 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[0][0][r] = (i16 < p.M && 4 * g + r < p.M) ? 0.f : s[0][0][r];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dp[i][t] *= s[i][t];        // dS^T = P^T * (dP^T - delta)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bf16x8 sf = pack_p(dp[i][0], dp[i][1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[i][dt] = mma16(kt.f[dt], sf, dq[i][dt]);
+  }
+}
+
+// phase B step: two sixteen-query sub-tiles at LDS row t0 * 16 against the wave's two key tiles (S orientation: the lane owns key
+// column i16 of each tile; rows 4g + r are queries, whose constants come from LDS as ready-made C operands).  Query rows >= R have
+// zero-filled Q / dO rows and zero constants (P = 1 times zeros); key lanes >= R only produce their own, discarded, columns.
+__device__ __forceinline__ void b5_dkv_step(f32x4 (&dk)[2][4], f32x4 (&dv)[2][4], const AP& p, const char* gQ, const char* gDO,
+                                            const float* sC, const float* sNd, const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2],
+                                            int t0, bool corner, int lane) {
+  const int g = lane >> 4, i16 = lane & 15;
+  f32x4 s[2][2], dp[2][2];
+  {
+    bf16x8 qr[2][2];
+    f32x4 c4[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      c4[t] = *reinterpret_cast<const f32x4*>(sC + (t0 + t) * 16 + 4 * g);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) qr[t][kk] = frag_rows(gQ, t0 + t, kk, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) s[i][t] = mma16(qr[t][1], kf[i][1], mma16(qr[t][0], kf[i][0], c4[t]));
+  }
+  {
+    bf16x8 dr[2][2];
+    f32x4 n4[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      n4[t] = *reinterpret_cast<const f32x4*>(sNd + (t0 + t) * 16 + 4 * g);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) dr[t][kk] = frag_rows(gDO, t0 + t, kk, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dp[i][t] = mma16(dr[t][1], vf[i][1], mma16(dr[t][0], vf[i][0], n4[t]));
+  }
+  B5TFrag qt, dot;
+  __builtin_amdgcn_sched_barrier(0);
+  b5_tfrag(dot, gDO + t0 * 16 * 128, lane);
+  b5_tfrag(qt, gQ + t0 * 16 * 128, lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[i][t][r] = __builtin_amdgcn_exp2f(s[i][t][r] * LOG2E);
+  if (corner && t0 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[0][0][r] = (i16 < p.M && 4 * g + r < p.M) ? 0.f : s[0][0][r];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dp[i][t] *= s[i][t];        // dS = P * (dP - delta)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bf16x8 pf = pack_p(s[i][0], s[i][1]), sf = pack_p(dp[i][0], dp[i][1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dv[i][dt] = mma16(dot.f[dt], pf, dv[i][dt]);
+      dk[i][dt] = mma16(qt.f[dt], sf, dk[i][dt]);
+    }
+  }
+}
+
+// column sums over the wave's finished rows of both tiles (values as stored: rounded): butterfly over the 16 row lanes, then one LDS
+// row per wave; the workgroup's fixed-order sum over the waves happens after the next barrier (b5_colsum_finish)
+__device__ __forceinline__ void b5_colsum_wave(f32x4 (&v)[4], float* red_row, int lane) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[dt][r] += __shfl_xor(v[dt][r], o, 64);
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(red_row + dt * 16 + 4 * (lane >> 4), v[dt]);
+  }
+}
+__device__ __forceinline__ void b5_colsum_finish(const float* red, float* dst, int d) {
+  float a = 0.f;
+#pragma unroll
+  for (int w = 0; w < B5W; ++w) a += red[w * DH + d];
+  dst[d] = a;
+}
+
+// the three bias column-sum rows of one problem (block 0 of its p.nq rows; the other blocks of the two-kernel layout are zero)
+__device__ __forceinline__ float* b5_cs_row(const AP& p, const Prob& pr) {
+  return p.cs + ((int64_t)(pr.b * p.N + pr.n) * p.nq) * (3 * p.H * DH) + pr.h * DH;
+}
+
+__global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* X = smem; char* Y = smem + 2 * B5_IMG;
+  float* sC = reinterpret_cast<float*>(smem + B5_OFF_STATS); float* sNd = sC + B5_ROWS;
+  float* red = reinterpret_cast<float*>(smem + B5_OFF_RED);
+  int* sNext = reinterpret_cast<int*>(smem + B5_OFF_NEXT);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int nt = (p.R + 15) / 16;                          // sixteen-row tiles of a problem (<= 13)
+  const int nsteps = (nt + 1) / 2;                         // 32-row steps; an odd last tile is paired with the pad tile
+  const bool active = wave < nt;                           // owns at least one real tile (tiles wave, wave + 8)
+  int prob = blockIdx.x, prev = -1;
+  if (prob >= p.nprob) return;
+  // the pad tile of the four images: never staged, zero for the whole launch
+  if (tid0 < 4 * 16 * 8) *reinterpret_cast<u32x4*>(smem + (tid0 >> 7) * B5_IMG + FG * 128 + (tid0 & 127) * 16) = u32x4{0, 0, 0, 0};
+  B5Own w;
+  {
+    const Prob pr(p, prob);
+    b5_stage_kv(X, p, pr, lane0, wave);
+    b5_load_own(w, p, pr, wave, lane0);
+  }
+  for (;;) {
+    // Every per-lane constant (LDS fragment addresses, loader offsets, row predicates) is re-derived per phase from a lane id the
+    // compiler cannot see through: hoisted out of the persistent loop they do not fit 256 registers, and a spill RELOAD is a vector
+    // memory operation -- its s_waitcnt vmcnt(0) drains the LDS-DMA queue, i.e. exposes the whole prefetch (measured: 208 us).
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    int tid = wave * 64 + lane, i16 = lane & 15, g = lane >> 4;
+    if (tid == 0) *sNext = atomicAdd(counter, 1) + (int)gridDim.x;
+    __syncthreads();                                       // X (K, V of prob) has landed; every wave is done with Y and `red`
+    const Prob pr(p, prob);
+    b5_stage_qdo(Y, p, pr, lane, wave);                    // lands during phase A
+    if (p.cs && prev >= 0 && tid < 2 * DH) {               // previous problem: dK / dV column sums
+      const Prob pv(p, prev);
+      float* row = b5_cs_row(p, pv);
+      if (tid < DH) b5_colsum_finish(red + B5W * DH, row + p.H * DH, tid);
+      else          b5_colsum_finish(red + 2 * B5W * DH, row + 2 * p.H * DH, tid - DH);
+    }
+    const bool corner = wave == 0 && pr.n != 0;
+    bf16x8 kf[2][2], vf[2][2];
+    {
+      // ---- phase A: dQ of the wave's query tiles; delta = sum_d dO * O from the fragments in registers (each of the 4 lanes of a
+      // row holds 16 of the 64 d); the row constants also go to LDS for phase B (rows >= R: zeros)
+      f32x4 c4[2], nd4[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float dl = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dl += (float)w.d[i][kk][e] * (float)w.o[i][kk][e];
+        dl = group_sum(dl);
+        const float c = -(w.m[i] + w.lg[i]);
+        c4[i] = f32x4{c, c, c, c}; nd4[i] = f32x4{-dl, -dl, -dl, -dl};
+        const int rq = (wave + B5W * i) * 16 + i16;
+        if (g == 0 && rq < B5_ROWS) { sC[rq] = c; sNd[rq] = -dl; }
+      }
+      f32x4 dq[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[i][dt] = f32x4{0, 0, 0, 0};
+      if (active)
+        for (int st = 0; st < nsteps; ++st) b5_dq_step(dq, p, X, X + B5_IMG, w, c4, nd4, 2 * st, corner, (2 * st + 2) * 16 > p.R, lane);
+      f32x4 cs[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) cs[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rq = (wave + B5W * i) * 16 + i16;
+        if (rq >= p.R) continue;
+        if (rq < p.M) {                                       // proxy query rows: per-frame partials, reduced later
+          float* part = p.ws1 + ((int64_t)prob * p.M + rq) * DH;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) store4(part + dt * 16 + 4 * g, dq[i][dt]);
+          continue;
+        }
+        bf16_t* base = p.dqkv + ((int64_t)pr.b * p.S + tok_of(p, pr.n, rq)) * p.ldqkv + pr.h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const f32x4 v = dq[i][dt] * p.q_scale;
+          store4(base + dt * 16 + 4 * g, v);
+          cs[dt] += round_bf16(v);
+        }
+      }
+      if (p.cs) b5_colsum_wave(cs, red + wave * DH, lane);
+      // the wave's own key rows for phase B, out of the image (X is overwritten after the barrier)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int t = wave + B5W * i < B5_ROWS / 16 ? wave + B5W * i : B5_ROWS / 16 - 1;      // (tiles past the image: the pad tile)
+          kf[i][kk] = frag_rows(X, t, kk, lane);
+          vf[i][kk] = frag_rows(X + B5_IMG, t, kk, lane);
+        }
+    }
+    __syncthreads();                                       // Y has landed; constants and dQ column sums are in LDS; X is free
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    tid = wave * 64 + lane; i16 = lane & 15; g = lane >> 4;
+    const int next = *sNext;
+    if (next < p.nprob) {
+      const Prob pn(p, next);
+      b5_stage_kv(X, p, pn, lane, wave);                   // lands during phase B
+    }
+    if (p.cs && tid < DH) {
+      float* row = b5_cs_row(p, pr);
+      b5_colsum_finish(red, row, tid);
+      for (int blk = 1; blk < p.nq; ++blk)                 // rows of the two-kernel layout this launch does not use
+        for (int j = 0; j < 3; ++j) row[(int64_t)blk * 3 * p.H * DH + j * p.H * DH + tid] = 0.f;
+    }
+    {
+      // ---- phase B: dK, dV of the wave's key tiles
+      f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[i][dt] = f32x4{0, 0, 0, 0}; dv[i][dt] = f32x4{0, 0, 0, 0}; }
+      if (active)
+        for (int st = 0; st < nsteps; ++st) b5_dkv_step(dk, dv, p, Y, Y + B5_IMG, sC, sNd, kf, vf, 2 * st, corner, lane);
+      // the next problem's own query rows: issued here, behind the step loop (48 registers the loop does not have), in front of the
+      // stores and the column sums that cover most of their latency
+      if (next < p.nprob) { const Prob pn(p, next); b5_load_own(w, p, pn, wave, lane); }
+      f32x4 ck[4], cv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { ck[dt] = f32x4{0, 0, 0, 0}; cv[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rk = (wave + B5W * i) * 16 + i16;
+        if (rk >= p.R) continue;
+        if (rk < p.M) {                                       // proxy keys: per-frame partials, reduced later
+          float* part = p.ws2 + ((int64_t)prob * p.M + rk) * (2 * DH);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, dk[i][dt]); store4(part + DH + dt * 16 + 4 * g, dv[i][dt]); }
+          continue;
+        }
+        bf16_t* base = p.dqkv + ((int64_t)pr.b * p.S + tok_of(p, pr.n, rk)) * p.ldqkv + pr.h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, dk[i][dt]);
+          store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, dv[i][dt]);
+          ck[dt] += round_bf16(dk[i][dt]); cv[dt] += round_bf16(dv[i][dt]);
+        }
+      }
+      if (p.cs) {
+        b5_colsum_wave(ck, red + (B5W + wave) * DH, lane);
+        b5_colsum_wave(cv, red + (2 * B5W + wave) * DH, lane);
+      }
+    }
+    prev = prob;
+    if (next >= p.nprob) break;
+    prob = next;
+  }
+  if (p.cs) {
+    __syncthreads();
+    const int tid = tid0;
+    if (tid < 2 * DH) {
+      const Prob pv(p, prev);
+      float* row = b5_cs_row(p, pv);
+      if (tid < DH) b5_colsum_finish(red + B5W * DH, row + p.H * DH, tid);
+      else          b5_colsum_finish(red + 2 * B5W * DH, row + 2 * p.H * DH, tid - DH);
+    }
+  }
+}
+
 int check_common(const char* name, int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L,
                  int64_t ldqkv, int64_t ldo, int32_t dtype) {
   XP_REQUIRE(dtype == XP_BF16 || dtype == XP_F32, "%s: bad dtype %d", name, dtype);
@@ -1123,7 +1579,7 @@ extern "C" size_t xp_attn_workspace_bytes(int32_t mode, int64_t B, int64_t H, in
   const int64_t delta = B * H * S;
   if (mode != XP_ATTN_PROXY) return (size_t)delta * sizeof(float);
   const int64_t P = B * H * N;
-  const int64_t fwd = P * M * PART, bwd = delta + P * M * DH + P * M * 2 * DH;
+  const int64_t fwd = P * M * PART, bwd = delta + P * M * DH + P * M * 2 * DH + 64;      // (+ the fused backward's problem counter)
   return (size_t)(fwd > bwd ? fwd : bwd) * sizeof(float);
 }
 
@@ -1226,11 +1682,40 @@ extern "C" int xp_attn_bwd2(const void* qkv, int64_t ldqkv, const void* out, con
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)P;
   p.cs = dqkv_colsum_partials; p.cs_main = (int)(B * N * p.nq);
-  const unsigned grid = (unsigned)(cdiv(p.nprob, 8) * 8 * p.nq);
-  attn_bwd_dq_kernel<<<grid, FTHR, 0, st>>>(p);          // also computes delta = rowsum(dO * O) into ws0
-  XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
-  attn_bwd_dkv_kernel<<<grid, FTHR, 0, st>>>(p);
-  XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
+  p.dbg = (xp_debug_flag("b5_own_ptr") ? 1 : 0) | (xp_debug_flag("b5_dma_old") ? 2 : 0);
+  // the fused kernel: the problems of attn_fwd3_kernel (one LDS group, at most 16 proxy rows, no padding mask) on a device that
+  // grants the dynamic-LDS opt-in; XPRETRAIN_DEBUG=attn_bwd_split keeps the two-kernel path (A/B and the cross-check test)
+  bool use5 = mode == XP_ATTN_PROXY && p.R <= FG && p.M <= 16 && !pad_mask && !xp_debug_flag("attn_bwd_split");
+  int ncu = 256;
+  if (use5) {
+    static std::mutex mu;
+    static int configured[64] = {0};                    // per device -- 0: not yet, > 0: CU count, -1: refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) use5 = false;
+    else {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!configured[dev]) {
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            B5_LDS) == hipSuccess;
+        configured[dev] = ok ? (n > 0 ? n : 256) : -1;
+      }
+      if (configured[dev] < 0) use5 = false; else ncu = configured[dev];
+    }
+  }
+  if (use5) {
+    int* counter = reinterpret_cast<int*>(p.ws2 + P * M * 2 * DH);
+    if (hipMemsetAsync(counter, 0, sizeof(int), st) != hipSuccess) { xp_set_error("xp_attn_bwd: counter reset failed"); return XP_ERR_LAUNCH; }
+    attn_bwd5_kernel<<<(unsigned)(p.nprob < ncu ? p.nprob : ncu), B5THR, B5_LDS, st>>>(p, counter);
+    XP_CHECK_LAUNCH("xp_attn_bwd(fused)");
+  } else {
+    const unsigned grid = (unsigned)(cdiv(p.nprob, 8) * 8 * p.nq);
+    attn_bwd_dq_kernel<<<grid, FTHR, 0, st>>>(p);          // also computes delta = rowsum(dO * O) into ws0
+    XP_CHECK_LAUNCH("xp_attn_bwd(dq)");
+    attn_bwd_dkv_kernel<<<grid, FTHR, 0, st>>>(p);
+    XP_CHECK_LAUNCH("xp_attn_bwd(dkv)");
+  }
   if (mode == XP_ATTN_PROXY) {
     attn_bwd_proxy_reduce_kernel<<<(unsigned)(B * H * M), 256, 0, st>>>(p);
     XP_CHECK_LAUNCH("xp_attn_bwd(proxy reduce)");
