@@ -42,7 +42,7 @@ struct AP {
   int nq, nprob;                        // forward: query blocks per problem, problems
   float q_scale;
   float* ws0; float* ws1; float* ws2;   // fwd: partials | bwd: delta, dq partials, dkv partials
-  int dbg;
+  unsigned long long* tr;               // xp_debug_set_attn_trace (fused backward): cycle stamps of one workgroup
   float* cs; int cs_main;               // bwd, optional: column-sum partial rows of dqkv [cs_main + B*M][3*H*64] (see xp_attn_bwd2)
 };
 
@@ -1120,32 +1120,30 @@ constexpr int B5_IMG = B5_ROWS * 128;                          // one operand im
 constexpr int B5_OFF_STATS = 4 * B5_IMG;                       // c[B5_ROWS] = -(m + log l), nd[B5_ROWS] = -delta
 constexpr int B5_OFF_RED = B5_OFF_STATS + 2 * B5_ROWS * 4;     // column-sum partials [3][B5W][DH]
 constexpr int B5_OFF_NEXT = B5_OFF_RED + 3 * B5W * DH * 4;
-constexpr int B5_LDS = B5_OFF_NEXT + 16;
+constexpr int B5_STG_ROW = 128 + 16;                           // output staging: 128-byte rows, skewed by 16 bytes against bank conflicts
+constexpr int B5_STG_WAVE = 32 * B5_STG_ROW;                   // one wave's two finished 16 x 64 tiles
+constexpr int B5_OFF_STG = B5_OFF_NEXT + 16;
+constexpr int B5_LDS = B5_OFF_STG + B5W * B5_STG_WAVE;
 
 // rows [0, FG) of one row-major operand (the 64 elements of a (token, head) slice; rows >= R read as zero) -> linear swizzled LDS
 // image by LDS-DMA, one wave instruction = 8 rows x 128 B.  The per-lane part of the source offset does not depend on the problem
 // (vrow: byte offset of the lane's row inside a 64-row block + its swizzled 16-byte chunk); the frame and the 64-row block ride in
 // the scalar offset, so a problem costs the loader no vector registers beyond the proxy rows of block 0 (voff0).
-__device__ __forceinline__ void b5_stage(char* img, __amdgpu_buffer_rsrc_t rs, unsigned ld_bytes, unsigned soff, unsigned vrow,
-                                         unsigned voff0, int R, unsigned frame_off, int lane, int wave, int dbg = 0, int M_ = 0) {
+// `j`: ONE of the four 64-row blocks (a wave instruction each): the caller spreads the pieces over its step loop -- issued in one
+// burst, the 8 instructions of a wave cost it ~3k cycles of queueing in front of the first MFMA (tools/attn_bwd_trace.py).
+__device__ __forceinline__ void b5_stage_piece(char* img, __amdgpu_buffer_rsrc_t rs, unsigned ld_bytes, unsigned soff, unsigned vrow,
+                                               unsigned voff0, int R, unsigned frame_off, int lane, int wave, int j) {
   typedef __attribute__((address_space(3))) char lds_c;
   constexpr int NPASS = FG / 8;
-#pragma unroll
-  for (int j = 0; j < (NPASS + B5W - 1) / B5W; ++j) {
-    const int pass = j * B5W + wave;
-    if (pass < NPASS) {
-      const int row = pass * 8 + (lane >> 3);
-      unsigned v = row < R ? (j == 0 ? voff0 : vrow) : 0xFFFFFF00u;
-      unsigned so = j == 0 ? soff : soff + frame_off + (unsigned)(j * 64) * ld_bytes;
-      if (dbg & 2) {
-        const int c = (lane & 7) ^ swz128(row);
-        const int tok = row >= M_ ? row + (int)(frame_off / ld_bytes) : row;
-        v = row < R ? (unsigned)tok * ld_bytes + c * 16 : 0xFFFFFF00u; so = soff;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(img + pass * 1024), 16, v, so, 0, 0);
-    }
+  const int pass = j * B5W + wave;
+  if (pass < NPASS) {
+    const int row = pass * 8 + (lane >> 3);
+    const unsigned v = row < R ? (j == 0 ? voff0 : vrow) : 0xFFFFFF00u;
+    const unsigned so = j == 0 ? soff : soff + frame_off + (unsigned)(j * 64) * ld_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_c*)(img + pass * 1024), 16, v, so, 0, 0);
   }
 }
+constexpr int B5_PIECES = (FG / 8 + B5W - 1) / B5W;            // 4
 struct B5Lane { unsigned vq, vo, v0q, v0o; };                 // per-lane source offsets for pitch ldqkv / ldo (block >= 1 / block 0)
 __device__ __forceinline__ void b5_lane_offsets(B5Lane& L, const AP& p, int n, int lane, int wave) {
   const int row = wave * 8 + (lane >> 3);                       // the lane's row inside a 64-row block
@@ -1156,16 +1154,19 @@ __device__ __forceinline__ void b5_lane_offsets(B5Lane& L, const AP& p, int n, i
   L.v0q = tok0 * (unsigned)(p.ldqkv * 2) + c16;
   L.v0o = tok0 * (unsigned)(p.ldo * 2) + c16;
 }
-__device__ __forceinline__ void b5_stage_kv(char* X, const AP& p, const Prob& pr, int lane, int wave) {
+// pieces [j0, j1) of the {K, V} image of problem pr / of its {Q, dO} image
+__device__ __forceinline__ void b5_stage_kv(char* X, const AP& p, const Prob& pr, int lane, int wave, int j0 = 0, int j1 = B5_PIECES) {
   const bf16_t* kbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + (int64_t)p.H * DH + pr.h * DH;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(kbase), 0, (unsigned)((int64_t)p.S * p.ldqkv * 2 - ((int64_t)p.H * DH + pr.h * DH) * 2), 0x00020000);
   B5Lane L; b5_lane_offsets(L, p, pr.n, lane, wave);
   const unsigned ld = (unsigned)(p.ldqkv * 2), fo = (unsigned)(pr.n * p.L) * ld;
-  b5_stage(X, rs, ld, 0, L.vq, L.v0q, p.R, fo, lane, wave, p.dbg, p.M);
-  b5_stage(X + B5_IMG, rs, ld, (unsigned)(p.H * DH * 2), L.vq, L.v0q, p.R, fo, lane, wave, p.dbg, p.M);
+  for (int j = j0; j < j1; ++j) {
+    b5_stage_piece(X, rs, ld, 0, L.vq, L.v0q, p.R, fo, lane, wave, j);
+    b5_stage_piece(X + B5_IMG, rs, ld, (unsigned)(p.H * DH * 2), L.vq, L.v0q, p.R, fo, lane, wave, j);
+  }
 }
-__device__ __forceinline__ void b5_stage_qdo(char* Y, const AP& p, const Prob& pr, int lane, int wave) {
+__device__ __forceinline__ void b5_stage_qdo(char* Y, const AP& p, const Prob& pr, int lane, int wave, int j0 = 0, int j1 = B5_PIECES) {
   const bf16_t* qbase = p.qkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
   const bf16_t* dobase = p.dout + (int64_t)pr.b * p.S * p.ldo + pr.h * DH;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
@@ -1174,8 +1175,10 @@ __device__ __forceinline__ void b5_stage_qdo(char* Y, const AP& p, const Prob& p
       const_cast<bf16_t*>(dobase), 0, (unsigned)(((int64_t)p.S * p.ldo - pr.h * DH) * 2), 0x00020000);
   B5Lane L; b5_lane_offsets(L, p, pr.n, lane, wave);
   const unsigned ldq = (unsigned)(p.ldqkv * 2), ldo = (unsigned)(p.ldo * 2);
-  b5_stage(Y, rq, ldq, 0, L.vq, L.v0q, p.R, (unsigned)(pr.n * p.L) * ldq, lane, wave, p.dbg, p.M);
-  b5_stage(Y + B5_IMG, rdo, ldo, 0, L.vo, L.v0o, p.R, (unsigned)(pr.n * p.L) * ldo, lane, wave, p.dbg, p.M);
+  for (int j = j0; j < j1; ++j) {
+    b5_stage_piece(Y, rq, ldq, 0, L.vq, L.v0q, p.R, (unsigned)(pr.n * p.L) * ldq, lane, wave, j);
+    b5_stage_piece(Y + B5_IMG, rdo, ldo, 0, L.vo, L.v0o, p.R, (unsigned)(pr.n * p.L) * ldo, lane, wave, j);
+  }
 }
 
 // the wave's own query rows (tiles wave, wave + 8; rows >= R: zeros) straight from global memory: Q, dO, O fragments and (m, log l)
@@ -1198,15 +1201,6 @@ __device__ __forceinline__ void b5_load_own(B5Own& w, const AP& p, const Prob& p
     const unsigned tok = (unsigned)tok_of(p, pr.n, ok ? rq_ : 0);
     const unsigned oq = ok ? tok * (unsigned)(p.ldqkv * 2) + g * 16 : 0xFFFFFF00u;
     const unsigned oo = ok ? tok * (unsigned)(p.ldo * 2) + g * 16 : 0xFFFFFF00u;
-    if (p.dbg & 1) {
-      const int64_t tk = (int64_t)pr.b * p.S + tok;
-      load_row_frag(w.q[i], p.qkv + tk * p.ldqkv + pr.h * DH, ok, g);
-      load_row_frag(w.d[i], p.dout + tk * p.ldo + pr.h * DH, ok, g);
-      load_row_frag(w.o[i], p.out + tk * p.ldo + pr.h * DH, ok, g);
-      const float* sp = p.stats + (((int64_t)pr.b * p.H + pr.h) * p.S + tok) * 2;
-      w.m[i] = ok ? sp[0] : 0.f; w.lg[i] = ok ? sp[1] : 0.f;
-      continue;
-    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       w.q[i][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, oq + kk * 64, 0, 0));
@@ -1229,16 +1223,19 @@ __device__ __forceinline__ void b5_tfrag(B5TFrag& t, const char* tile, int lane)
 // query column i16 of each tile; rows 4g + r are keys).  tail: the step reaches past key R (those P are forced to zero: their K rows
 // are zero-filled, but P * 0 must not see an overflowed P).  corner: the wave's first tile holds the proxy query rows and this is a
 // frame n != 0 -- proxy x proxy scores are counted in frame 0 only.
-__device__ __forceinline__ void b5_dq_step(f32x4 (&dq)[2][4], const AP& p, const char* gK, const char* gV, const B5Own& w,
-                                           const f32x4 (&c4)[2], const f32x4 (&nd4)[2], int t0, bool corner, bool tail, int lane) {
+template <bool TAIL>
+__device__ __forceinline__ void b5_dq_step(f32x4 (&dq)[2][4], const AP& p, const char* tK, const B5Own& w,
+                                           const f32x4 (&c4)[2], const f32x4 (&nd4)[2], int t0, bool corner, int lane) {
+  // tK: the K image advanced to the step's first row (a multiple of 16 rows keeps the swizzle phase); V is B5_IMG further
   const int g = lane >> 4, i16 = lane & 15;
+  const char* tV = tK + B5_IMG;
   f32x4 s[2][2], dp[2][2];
   {
     bf16x8 kf[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) kf[t][kk] = frag_rows(gK, t0 + t, kk, lane);
+      for (int kk = 0; kk < 2; ++kk) kf[t][kk] = frag_rows(tK, t, kk, lane);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1249,7 +1246,7 @@ __device__ __forceinline__ void b5_dq_step(f32x4 (&dq)[2][4], const AP& p, const
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) vf[t][kk] = frag_rows(gV, t0 + t, kk, lane);
+      for (int kk = 0; kk < 2; ++kk) vf[t][kk] = frag_rows(tV, t, kk, lane);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1257,15 +1254,15 @@ __device__ __forceinline__ void b5_dq_step(f32x4 (&dq)[2][4], const AP& p, const
   }
   B5TFrag kt;
   __builtin_amdgcn_sched_barrier(0);
-  b5_tfrag(kt, gK + t0 * 16 * 128, lane);                  // row shift by a multiple of 16 keeps the swizzle phase
+  b5_tfrag(kt, tK, lane);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[i][t][r] = __builtin_amdgcn_exp2f(s[i][t][r] * LOG2E);
-  if (tail) {
-    const int klim = p.R - t0 * 16 - 4 * g;                // the lane's key rows are t0*16 + 16t + 4g + r: valid iff 16t + r < klim
+  if constexpr (TAIL) {                                    // (its own instantiation: as a run-time flag hipcc if-converts the selects
+    const int klim = p.R - t0 * 16 - 4 * g;                //  into EVERY step.)  The lane's key rows are t0*16 + 16t + 4g + r
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1294,19 +1291,21 @@ __device__ __forceinline__ void b5_dq_step(f32x4 (&dq)[2][4], const AP& p, const
 // phase B step: two sixteen-query sub-tiles at LDS row t0 * 16 against the wave's two key tiles (S orientation: the lane owns key
 // column i16 of each tile; rows 4g + r are queries, whose constants come from LDS as ready-made C operands).  Query rows >= R have
 // zero-filled Q / dO rows and zero constants (P = 1 times zeros); key lanes >= R only produce their own, discarded, columns.
-__device__ __forceinline__ void b5_dkv_step(f32x4 (&dk)[2][4], f32x4 (&dv)[2][4], const AP& p, const char* gQ, const char* gDO,
-                                            const float* sC, const float* sNd, const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2],
-                                            int t0, bool corner, int lane) {
+__device__ __forceinline__ void b5_dkv_step(f32x4 (&dk)[2][4], f32x4 (&dv)[2][4], const AP& p, const char* tQ, const float* tC,
+                                            const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2], int t0, bool corner, int lane) {
+  // tQ: the Q image advanced to the step's first row (dO is B5_IMG further); tC: the row constants -(m + log l) advanced likewise
+  // (-delta is B5_ROWS floats further) -- every read of the step is one of a few per-lane bases plus an immediate
   const int g = lane >> 4, i16 = lane & 15;
+  const char* tD = tQ + B5_IMG;
   f32x4 s[2][2], dp[2][2];
   {
     bf16x8 qr[2][2];
     f32x4 c4[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      c4[t] = *reinterpret_cast<const f32x4*>(sC + (t0 + t) * 16 + 4 * g);
+      c4[t] = *reinterpret_cast<const f32x4*>(tC + t * 16 + 4 * g);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) qr[t][kk] = frag_rows(gQ, t0 + t, kk, lane);
+      for (int kk = 0; kk < 2; ++kk) qr[t][kk] = frag_rows(tQ, t, kk, lane);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1318,9 +1317,9 @@ __device__ __forceinline__ void b5_dkv_step(f32x4 (&dk)[2][4], f32x4 (&dv)[2][4]
     f32x4 n4[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      n4[t] = *reinterpret_cast<const f32x4*>(sNd + (t0 + t) * 16 + 4 * g);
+      n4[t] = *reinterpret_cast<const f32x4*>(tC + B5_ROWS + t * 16 + 4 * g);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) dr[t][kk] = frag_rows(gDO, t0 + t, kk, lane);
+      for (int kk = 0; kk < 2; ++kk) dr[t][kk] = frag_rows(tD, t, kk, lane);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1329,8 +1328,8 @@ __device__ __forceinline__ void b5_dkv_step(f32x4 (&dk)[2][4], f32x4 (&dv)[2][4]
   }
   B5TFrag qt, dot;
   __builtin_amdgcn_sched_barrier(0);
-  b5_tfrag(dot, gDO + t0 * 16 * 128, lane);
-  b5_tfrag(qt, gQ + t0 * 16 * 128, lane);
+  b5_tfrag(dot, tD, lane);
+  b5_tfrag(qt, tQ, lane);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1358,18 +1357,46 @@ __device__ __forceinline__ void b5_dkv_step(f32x4 (&dk)[2][4], f32x4 (&dv)[2][4]
   }
 }
 
-// column sums over the wave's finished rows of both tiles (values as stored: rounded): butterfly over the 16 row lanes, then one LDS
-// row per wave; the workgroup's fixed-order sum over the waves happens after the next barrier (b5_colsum_finish)
-__device__ __forceinline__ void b5_colsum_wave(f32x4 (&v)[4], float* red_row, int lane) {
+// The wave's two finished 16 x 64 tiles (C layout: the lane owns row i16 of each tile, d = 16 dt + 4g + r) leave through the wave's
+// LDS scratch: written as bf16 rows, read back as 16-byte chunks, stored as FULL 128-byte lines -- one store instruction covers 8
+// rows (8 lines) where the row-per-lane form touched 16 lines with 8 bytes per lane and the CU's 8 waves queued behind each other's
+// 16 store instructions (8-11k cycles per problem, tools/attn_bwd_trace.py).  Rows < M (proxy rows: fp32 partials, written by the
+// caller) and rows >= R are skipped.  cs[e]: the column sums of the rows stored (values as stored), columns 8 (lane & 7) + e,
+// summed over the lane's rows; b5_colsum_wave finishes them over the 8 row lanes.
+__device__ __forceinline__ void b5_store_tiles(const f32x4 (&acc)[2][4], float scale, char* stg, bf16_t* colbase, const AP& p, int n,
+                                               int wave, int lane, float (&cs)[8]) {
+  const int i16 = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int o = 1; o < 16; o <<= 1)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = acc[i][dt] * scale;
+      const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(stg + (i * 16 + i16) * B5_STG_ROW + dt * 32 + g * 8) = o;
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[dt][r] += __shfl_xor(v[dt][r], o, 64);
-  if ((lane & 15) == 0) {
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store4(red_row + dt * 16 + 4 * (lane >> 4), v[dt]);
+  for (int ps = 0; ps < 4; ++ps) {
+    const int rr = (wave + B5W * (ps >> 1)) * 16 + (ps & 1) * 8 + (lane >> 3);      // problem row of staging row 8 ps + (lane >> 3)
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (ps * 8 + (lane >> 3)) * B5_STG_ROW + (lane & 7) * 16);
+    if (rr >= p.M && rr < p.R) {
+      *reinterpret_cast<bf16x8*>(colbase + (int64_t)tok_of(p, n, rr) * p.ldqkv + (lane & 7) * 8) = v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += (float)v[e];
+    }
+  }
+}
+// column sums of one wave: over the 8 row lanes (lane >> 3), then one LDS row per wave; the workgroup's fixed-order sum over the
+// waves happens after the next barrier (b5_colsum_finish)
+__device__ __forceinline__ void b5_colsum_wave(float (&cs)[8], float* red_row, int lane) {
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] += __shfl_xor(cs[e], o, 64);
+  if (lane < 8) {
+    store4(red_row + lane * 8, f32x4{cs[0], cs[1], cs[2], cs[3]});
+    store4(red_row + lane * 8 + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
   }
 }
 __device__ __forceinline__ void b5_colsum_finish(const float* red, float* dst, int d) {
@@ -1390,6 +1417,7 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
   float* sC = reinterpret_cast<float*>(smem + B5_OFF_STATS); float* sNd = sC + B5_ROWS;
   float* red = reinterpret_cast<float*>(smem + B5_OFF_RED);
   int* sNext = reinterpret_cast<int*>(smem + B5_OFF_NEXT);
+  char* stg = smem + B5_OFF_STG + (threadIdx.x >> 6) * B5_STG_WAVE;
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int nt = (p.R + 15) / 16;                          // sixteen-row tiles of a problem (<= 13)
@@ -1405,7 +1433,12 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
     b5_stage_kv(X, p, pr, lane0, wave);
     b5_load_own(w, p, pr, wave, lane0);
   }
+  unsigned long long* tr = (p.tr && (int)blockIdx.x == (int)gridDim.x / 2 && (wave == 0 || wave == 7) && lane0 == 0)
+                               ? p.tr + (wave ? 64 : 0) : nullptr;
+  int it = 0;
+#define B5_STAMP(k) do { if (tr && it < 8) tr[it * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   for (;;) {
+    B5_STAMP(0);
     // Every per-lane constant (LDS fragment addresses, loader offsets, row predicates) is re-derived per phase from a lane id the
     // compiler cannot see through: hoisted out of the persistent loop they do not fit 256 registers, and a spill RELOAD is a vector
     // memory operation -- its s_waitcnt vmcnt(0) drains the LDS-DMA queue, i.e. exposes the whole prefetch (measured: 208 us).
@@ -1414,8 +1447,8 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
     int tid = wave * 64 + lane, i16 = lane & 15, g = lane >> 4;
     if (tid == 0) *sNext = atomicAdd(counter, 1) + (int)gridDim.x;
     __syncthreads();                                       // X (K, V of prob) has landed; every wave is done with Y and `red`
+    B5_STAMP(1);
     const Prob pr(p, prob);
-    b5_stage_qdo(Y, p, pr, lane, wave);                    // lands during phase A
     if (p.cs && prev >= 0 && tid < 2 * DH) {               // previous problem: dK / dV column sums
       const Prob pv(p, prev);
       float* row = b5_cs_row(p, pv);
@@ -1446,29 +1479,29 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[i][dt] = f32x4{0, 0, 0, 0};
-      if (active)
-        for (int st = 0; st < nsteps; ++st) b5_dq_step(dq, p, X, X + B5_IMG, w, c4, nd4, 2 * st, corner, (2 * st + 2) * 16 > p.R, lane);
-      f32x4 cs[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) cs[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rq = (wave + B5W * i) * 16 + i16;
-        if (rq >= p.R) continue;
-        if (rq < p.M) {                                       // proxy query rows: per-frame partials, reduced later
-          float* part = p.ws1 + ((int64_t)prob * p.M + rq) * DH;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) store4(part + dt * 16 + 4 * g, dq[i][dt]);
-          continue;
-        }
-        bf16_t* base = p.dqkv + ((int64_t)pr.b * p.S + tok_of(p, pr.n, rq)) * p.ldqkv + pr.h * DH;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const f32x4 v = dq[i][dt] * p.q_scale;
-          store4(base + dt * 16 + 4 * g, v);
-          cs[dt] += round_bf16(v);
-        }
+      B5_STAMP(2);
+      // Y = {Q, dO} of this problem lands during phase A: one piece pair per step (every wave issues its pieces, active or not).
+      // The one step that reaches past key R is peeled (its selects in its own instantiation, outside the loop).
+      const int nfull = p.R / 32 < nsteps ? p.R / 32 : nsteps;
+      int st = 0;
+      for (; st < nfull; ++st) {
+        if (st < B5_PIECES) b5_stage_qdo(Y, p, pr, lane, wave, st, st + 1);
+        if (active) b5_dq_step<false>(dq, p, X + st * (32 * 128), w, c4, nd4, 2 * st, corner, lane);
       }
+      if (st < nsteps) {
+        if (st < B5_PIECES) b5_stage_qdo(Y, p, pr, lane, wave, st, st + 1);
+        if (active) b5_dq_step<true>(dq, p, X + st * (32 * 128), w, c4, nd4, 2 * st, corner, lane);
+        ++st;
+      }
+      if (st < B5_PIECES) b5_stage_qdo(Y, p, pr, lane, wave, st, B5_PIECES);
+      B5_STAMP(3);
+      if (wave == 0 && i16 < p.M && i16 < p.R) {              // proxy query rows: per-frame partials, reduced later
+        float* part = p.ws1 + ((int64_t)prob * p.M + i16) * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4(part + dt * 16 + 4 * g, dq[0][dt]);
+      }
+      float cs[8];
+      b5_store_tiles(dq, p.q_scale, stg, p.dqkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH, p, pr.n, wave, lane, cs);
       if (p.cs) b5_colsum_wave(cs, red + wave * DH, lane);
       // the wave's own key rows for phase B, out of the image (X is overwritten after the barrier)
 #pragma unroll
@@ -1480,15 +1513,13 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
           vf[i][kk] = frag_rows(X + B5_IMG, t, kk, lane);
         }
     }
+    B5_STAMP(4);
     __syncthreads();                                       // Y has landed; constants and dQ column sums are in LDS; X is free
+    B5_STAMP(5);
     lane = lane0;
     asm volatile("" : "+v"(lane));
     tid = wave * 64 + lane; i16 = lane & 15; g = lane >> 4;
     const int next = *sNext;
-    if (next < p.nprob) {
-      const Prob pn(p, next);
-      b5_stage_kv(X, p, pn, lane, wave);                   // lands during phase B
-    }
     if (p.cs && tid < DH) {
       float* row = b5_cs_row(p, pr);
       b5_colsum_finish(red, row, tid);
@@ -1502,41 +1533,40 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[i][dt] = f32x4{0, 0, 0, 0}; dv[i][dt] = f32x4{0, 0, 0, 0}; }
-      if (active)
-        for (int st = 0; st < nsteps; ++st) b5_dkv_step(dk, dv, p, Y, Y + B5_IMG, sC, sNd, kf, vf, 2 * st, corner, lane);
+      // X = {K, V} of the NEXT problem lands during phase B, one piece pair per step.  The step's LDS offsets go through an opaque
+      // scalar: the Y images and the row constants live above the 64 KiB an LDS instruction's immediate reaches, and hipcc otherwise
+      // re-associates every read into (lane part + step) + image constant -- one v_add per read, 25 per step.
+      for (int st = 0; st < nsteps || st < B5_PIECES; ++st) {
+        if (st < B5_PIECES && next < p.nprob) { const Prob pn(p, next); b5_stage_kv(X, p, pn, lane, wave, st, st + 1); }
+        if (active && st < nsteps) {
+          unsigned yo = 2u * B5_IMG + (unsigned)st * (32 * 128), co = (unsigned)B5_OFF_STATS + (unsigned)st * (32 * 4);
+          asm volatile("" : "+s"(yo), "+s"(co));
+          b5_dkv_step(dk, dv, p, smem + yo, reinterpret_cast<const float*>(smem + co), kf, vf, 2 * st, corner, lane);
+        }
+      }
+      B5_STAMP(6);
       // the next problem's own query rows: issued here, behind the step loop (48 registers the loop does not have), in front of the
       // stores and the column sums that cover most of their latency
       if (next < p.nprob) { const Prob pn(p, next); b5_load_own(w, p, pn, wave, lane); }
-      f32x4 ck[4], cv[4];
+      if (wave == 0 && i16 < p.M && i16 < p.R) {              // proxy keys: per-frame partials, reduced later
+        float* part = p.ws2 + ((int64_t)prob * p.M + i16) * (2 * DH);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) { ck[dt] = f32x4{0, 0, 0, 0}; cv[dt] = f32x4{0, 0, 0, 0}; }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rk = (wave + B5W * i) * 16 + i16;
-        if (rk >= p.R) continue;
-        if (rk < p.M) {                                       // proxy keys: per-frame partials, reduced later
-          float* part = p.ws2 + ((int64_t)prob * p.M + rk) * (2 * DH);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, dk[i][dt]); store4(part + DH + dt * 16 + 4 * g, dv[i][dt]); }
-          continue;
-        }
-        bf16_t* base = p.dqkv + ((int64_t)pr.b * p.S + tok_of(p, pr.n, rk)) * p.ldqkv + pr.h * DH;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          store4(base + (int64_t)p.H * DH + dt * 16 + 4 * g, dk[i][dt]);
-          store4(base + (int64_t)2 * p.H * DH + dt * 16 + 4 * g, dv[i][dt]);
-          ck[dt] += round_bf16(dk[i][dt]); cv[dt] += round_bf16(dv[i][dt]);
-        }
+        for (int dt = 0; dt < 4; ++dt) { store4(part + dt * 16 + 4 * g, dk[0][dt]); store4(part + DH + dt * 16 + 4 * g, dv[0][dt]); }
       }
-      if (p.cs) {
-        b5_colsum_wave(ck, red + (B5W + wave) * DH, lane);
-        b5_colsum_wave(cv, red + (2 * B5W + wave) * DH, lane);
-      }
+      bf16_t* colbase = p.dqkv + (int64_t)pr.b * p.S * p.ldqkv + pr.h * DH;
+      float cs[8];
+      b5_store_tiles(dk, 1.0f, stg, colbase + (int64_t)p.H * DH, p, pr.n, wave, lane, cs);
+      if (p.cs) b5_colsum_wave(cs, red + (B5W + wave) * DH, lane);
+      b5_store_tiles(dv, 1.0f, stg, colbase + (int64_t)2 * p.H * DH, p, pr.n, wave, lane, cs);
+      if (p.cs) b5_colsum_wave(cs, red + (2 * B5W + wave) * DH, lane);
     }
+    B5_STAMP(7);
+    ++it;
     prev = prob;
     if (next >= p.nprob) break;
     prob = next;
   }
+#undef B5_STAMP
   if (p.cs) {
     __syncthreads();
     const int tid = tid0;
@@ -1682,7 +1712,7 @@ extern "C" int xp_attn_bwd2(const void* qkv, int64_t ldqkv, const void* out, con
   hipStream_t st = (hipStream_t)stream;
   p.nq = (int)cdiv(p.R, FQ); p.nprob = (int)P;
   p.cs = dqkv_colsum_partials; p.cs_main = (int)(B * N * p.nq);
-  p.dbg = (xp_debug_flag("b5_own_ptr") ? 1 : 0) | (xp_debug_flag("b5_dma_old") ? 2 : 0);
+  p.tr = reinterpret_cast<unsigned long long*>(g_attn_trace);
   // the fused kernel: the problems of attn_fwd3_kernel (one LDS group, at most 16 proxy rows, no padding mask) on a device that
   // grants the dynamic-LDS opt-in; XPRETRAIN_DEBUG=attn_bwd_split keeps the two-kernel path (A/B and the cross-check test)
   bool use5 = mode == XP_ATTN_PROXY && p.R <= FG && p.M <= 16 && !pad_mask && !xp_debug_flag("attn_bwd_split");
