@@ -161,3 +161,4 @@ def test_backward_with_fp32_side_rows(rows, S, M, stride):
     assert torch.equal(dx1, dx)
     assert report("ln bwd side dgamma (deferred)", dg1, dg, 2e-6) <= 2e-6
     assert report("ln bwd side dx colsum", dxs, dx.double().sum(0), 3e-3) <= 3e-3
+

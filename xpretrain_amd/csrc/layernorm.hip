@@ -376,6 +376,8 @@ int ln_bwd_launch(const char* name, const void* dy, int64_t lddy, const void* x,
                                                   lddres, (T*)dx, lddx, part, rows, (int)cols, side)
 #define XP_LN_BWD_NJ(T, D)                                                                                            \
   do { if (nj == 1) XP_LN_BWD(T, 1, D); else if (nj == 2) XP_LN_BWD(T, 2, D); else if (nj == 3) XP_LN_BWD(T, 3, D); else XP_LN_BWD(T, 4, D); } while (0)
+  // (16-byte accesses -- 8 elements per lane -- were measured in round 6 and are no faster, alone or in the step: the kernel moves
+  //  4.8-5.3 TB/s as it is; tools/experiments/ln_bwd_wide.hip, profiles/r06f_*)
   if (dtype == XP_BF16) { if (dxs == 2) XP_LN_BWD_NJ(bf16_t, 2); else if (dxs) XP_LN_BWD_NJ(bf16_t, 1); else XP_LN_BWD_NJ(bf16_t, 0); }
   else                  { if (dxs == 2) XP_LN_BWD_NJ(float, 2);  else if (dxs) XP_LN_BWD_NJ(float, 1);  else XP_LN_BWD_NJ(float, 0); }
 #undef XP_LN_BWD_NJ
