@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--txt-len", type=int, default=32)
+    ap.add_argument("--opt-overlap", type=int, default=3, help="K >= 0: AdamW updates the encoder layers >= K of both towers on a stream of "
+                    "its own and the next forward waits for them in front of layer K (optimization.AdamW.overlap_next_forward; default 3: -0.1 ms per step, profiles/r06k_*); -1: off")
     ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step in a HIP graph and replay it "
                     "(works; measured 23.3 vs 23.1 ms/step eager on MI355X -- the step is GPU-bound and replaying a "
                     "600-node multi-stream graph costs the host as much as the eager launches); 0 (default): eager")
@@ -404,6 +406,8 @@ def main():
     LR, TOTAL_STEPS = 5e-6, 100000
     groups = build_e2e_optimizer_w_lr_mul(list(model.named_parameters()), LR, 0.05, lr_mul=1, lr_mul_prefix="")
     opt = AdamW([g for g in groups if g["params"]], lr=LR, betas=(0.9, 0.98))
+    if a.opt_overlap >= 0 and a.graph != 1:
+        opt.overlap_next_forward(model, a.opt_overlap)
     sched_step = [1000]      # start past the warmup so the synthetic loss moves
     video, ids, mask = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank)
     batches = None

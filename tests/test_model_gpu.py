@@ -465,3 +465,51 @@ def test_inference_forward_gathers_patches_in_the_gemm(monkeypatch):
     model.train()
     model(video, ids, mask)["vis_features"].sum().backward()  # training: the matrix is needed for dW
     assert calls and model.clipmodel.vision_model.embeddings.patch_embedding.weight.grad is not None
+
+
+@pytest.mark.parametrize("first_late", [0, 1, 2])
+def test_optimizer_overlapping_the_next_forward_trains_bit_identically(first_late):
+    """AdamW.overlap_next_forward: the update of the encoder layers >= K of both towers runs on a stream of its own and the NEXT
+    forward waits for it in front of layer K (functional.LATE_WEIGHTS).  Four training steps (4 layers per tower, clip active) must
+    leave the plain optimizer's parameters, moments, losses and gradient norms -- the same kernel on the same values; the launch
+    partition reorders the norm's chunk partials, so the clip factor may differ in its last bit (1e-6 relative) -- and state_dict()
+    readers wait for the late update too (a reader that did not would see the previous step's weights: 1e-3 relative)."""
+    from xpretrain_amd.modeling import VidCLIP
+    from xpretrain_amd.optimization import AdamW, NCELearnableTempLoss, build_e2e_optimizer_w_lr_mul
+    from xpretrain_amd import functional as XF
+    cfgd = O.hf_config_dict(128, 2, 4, 256, 16, 32, 128, 2, 4, 256, 120, 16, 64)
+    video, ids, mask = [t.cuda() for t in O.synthetic_inputs(4, 2, 32, 8, vocab=120)]
+
+    def train(K):
+        torch.manual_seed(11)
+        model = VidCLIP(_Args(cfgd, 2)).cuda().train()
+        groups = build_e2e_optimizer_w_lr_mul(list(model.named_parameters()), 1e-4, 0.05, lr_mul=1, lr_mul_prefix="")
+        opt = AdamW([g for g in groups if g["params"]], lr=1e-4, betas=(0.9, 0.98))
+        if K is not None:
+            opt.overlap_next_forward(model, K)
+        loss_fn, trace = NCELearnableTempLoss(), []
+        for _ in range(4):          # (a short, stable run: at lr 1e-3 this toy model amplifies the clip factor's last bit to 1e-4 in 4 steps)
+            out = model(video, ids, mask)
+            loss = loss_fn(out["vis_features"], out["text_features"], model.clipmodel.logit_scale)
+            loss.backward()
+            norm = opt.clip_and_step(0.05)
+            if K is not None:
+                assert XF.LATE_WEIGHTS["event"] is not None and XF.LATE_WEIGHTS["first_layer"] == K
+            opt.zero_grad(set_to_none=True)
+            trace.append((loss.detach().clone(), norm.clone()))
+        sd = {k: v.clone() for k, v in model.state_dict().items()}                 # (pre-hook: waits for the late update)
+        osd = opt.state_dict()["state"]
+        moments = [osd[i][k].clone() for i in sorted(osd) for k in ("exp_avg", "exp_avg_sq")]
+        XF.LATE_WEIGHTS["event"] = None
+        return trace, sd, moments
+    t0, sd0, m0 = train(None)
+    t1, sd1, m1 = train(first_late)
+    for (l0, n0), (l1, n1) in zip(t0, t1):
+        torch.testing.assert_close(l1, l0, rtol=2e-6, atol=0)
+        torch.testing.assert_close(n1, n0, rtol=2e-6, atol=0)
+    for k in sd0:
+        if sd0[k].is_floating_point():
+            torch.testing.assert_close(sd1[k], sd0[k], rtol=1e-5, atol=1e-7, msg=k)
+    assert len(m0) == len(m1)
+    for a, b in zip(m0, m1):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-9)

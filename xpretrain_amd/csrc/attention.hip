@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(B5THR, 2) void attn_bwd5_kernel(AP p, int* counter)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     int tid = wave * 64 + lane, i16 = lane & 15, g = lane >> 4;
-    if (tid == 0) *sNext = atomicAdd(counter, 1) + (int)gridDim.x;
+    if (tid == 0) *sNext = counter ? atomicAdd(counter, 1) + (int)gridDim.x : prob + (int)gridDim.x;
     __syncthreads();                                       // X (K, V of prob) has landed; every wave is done with Y and `red`
     B5_STAMP(1);
     const Prob pr(p, prob);
@@ -1736,7 +1736,8 @@ extern "C" int xp_attn_bwd2(const void* qkv, int64_t ldqkv, const void* out, con
   }
   if (use5) {
     int* counter = reinterpret_cast<int*>(p.ws2 + P * M * 2 * DH);
-    if (hipMemsetAsync(counter, 0, sizeof(int), st) != hipSuccess) { xp_set_error("xp_attn_bwd: counter reset failed"); return XP_ERR_LAUNCH; }
+    if (xp_debug_flag("attn_bwd_static")) counter = nullptr;          // (A/B: problems b, b + grid, ... per workgroup, no counter)
+    else if (hipMemsetAsync(counter, 0, sizeof(int), st) != hipSuccess) { xp_set_error("xp_attn_bwd: counter reset failed"); return XP_ERR_LAUNCH; }
     attn_bwd5_kernel<<<(unsigned)(p.nprob < ncu ? p.nprob : ncu), B5THR, B5_LDS, st>>>(p, counter);
     XP_CHECK_LAUNCH("xp_attn_bwd(fused)");
   } else {

@@ -802,9 +802,20 @@ extern "C" int32_t xp_get_cu_budget(void) { return g_cu_budget; }
 // gradient -- the last of the layer, the one the join waits for -- has a sharp optimum at 6 (4: +0.27 ms, 9: +0.24), fc1 / fc2 want 3
 // (4: +0.10, 5: +0.20), out_proj is flat between 12 and 19 (27: +0.08): 4/6/19 -> 3/6/12 is another -0.16 ms.
 constexpr int64_t XP_SPLITK_FILL = 176, XP_SPLITK_FILL_SLACK = 112;
+// XPRETRAIN_SPLITK_FILL=general[xslack] (e.g. 208x144): the A/B switch of the two fills (tools/instep_ab.py)
+static int64_t g_fill[2] = {XP_SPLITK_FILL, XP_SPLITK_FILL_SLACK};
+static const bool g_fill_env = [] {
+  const char* e = getenv("XPRETRAIN_SPLITK_FILL");
+  if (!e) return false;
+  int a = 0, b = 0;
+  const int n = sscanf(e, "%d%*[,x]%d", &a, &b);
+  if (n >= 1 && a >= 9 && a <= 256) g_fill[0] = a;
+  if (n >= 2 && b >= 9 && b <= 256) g_fill[1] = b;
+  return true;
+}();
 static int32_t auto_split_fill(const XpGemmDesc* d, int64_t fill);
-extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) { return auto_split_fill(d, XP_SPLITK_FILL); }
-extern "C" int32_t xp_gemm_auto_split_slack(const XpGemmDesc* d) { return auto_split_fill(d, XP_SPLITK_FILL_SLACK); }
+extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) { return auto_split_fill(d, g_fill[0]); }
+extern "C" int32_t xp_gemm_auto_split_slack(const XpGemmDesc* d) { return auto_split_fill(d, g_fill[1]); }
 
 static int32_t auto_split_fill(const XpGemmDesc* d, int64_t fill) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 1;

@@ -250,6 +250,31 @@ def _native_ok(x, vecs, mats, pad_mask) -> bool:
     return True
 
 
+# ---- weights the optimizer is still writing (optimization.AdamW(overlap=...)) ---------------------------------------------------
+# AdamW.step can run the update of the encoder layers >= K of both towers on a stream of its own, so that the HBM-bound optimizer
+# pass overlaps the MFMA-bound first layers of the NEXT forward instead of standing between two steps.  It leaves the event here;
+# CLIPEncoder.forward makes every stream that is about to run layer K wait for it.  Anything else that reads those parameters outside a
+# model forward (state_dict(), a checkpoint writer, an evaluation with other code) calls join_late_weights() first -- the model's
+# state_dict pre-hook and utils.load_save do.
+LATE_WEIGHTS = {"event": None, "first_layer": 0}
+
+
+def wait_late_weights(layer_index, *streams):
+    """Before encoder layer ``layer_index`` runs on ``streams`` (default: the current stream)."""
+    ev = LATE_WEIGHTS["event"]
+    if ev is None or layer_index != LATE_WEIGHTS["first_layer"]:
+        return
+    for st in (streams or (torch.cuda.current_stream(),)):
+        st.wait_event(ev)
+
+
+def join_late_weights():
+    """The current stream waits for the optimizer's late update (no-op when none is pending)."""
+    ev = LATE_WEIGHTS["event"]
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 # XPRETRAIN_FWD_SPLIT=0: the whole batch as one chain (A/B switch for the two half-batch chains of the video tower's forward)
 FWD_SPLIT = os.environ.get("XPRETRAIN_FWD_SPLIT", "1") != "0"
 FWD_SPLIT_MIN_ROWS = 8192          # below this a half-batch launch no longer fills the chip beside its twin

@@ -251,7 +251,9 @@ class CLIPEncoder(nn.Module):
                 and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] % 8 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS
                 and not _has_forward_hooks(self.layers)):     # (a hook would read a layer's output before the second chain wrote it)
             split = XF.ForwardSplit(x.device)
-        for layer in self.layers:
+        for li, layer in enumerate(self.layers):
+            if XF.LATE_WEIGHTS["event"] is not None and x.is_cuda:      # the optimizer's overlapped update of the layers >= K (XF.LATE_WEIGHTS)
+                XF.wait_late_weights(li, *((torch.cuda.current_stream(x.device), split.stream) if split is not None else ()))
             if ckpt:
                 # reference CLIP_ViP.py:675-690 (torch.utils.checkpoint around every encoder layer): the layer's saved-activation
                 # arena is dropped after the forward and rebuilt by re-running the layer when its backward starts -- the same
@@ -535,6 +537,8 @@ class CLIPModel(CLIPPreTrainedModel):
 
     def __init__(self, config):
         super().__init__(config)
+        # parameters the optimizer may still be writing on its own stream (XF.LATE_WEIGHTS): state_dict() readers wait
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: XF.join_late_weights())
         text_config, vision_config = config.text_config, config.vision_config
         additional_vision_config = getattr(config, "vision_additional_config", None)
         self.projection_dim = config.projection_dim

@@ -9,6 +9,11 @@ Mirrors ``src/optimization/adamw.py:11-103`` (``AdamW(params, lr, betas, eps=1e-
   is left in ``last_grad_norm`` (device scalar, no host sync).  The clipped gradients are not written back.
 * the compute-dtype copies of the weights (``functional.WEIGHTS``) are rewritten by the same kernel, so no cast
   kernels run in the next forward.
+* ``overlap_next_forward(model, first_late_layer=K)``: the update of the encoder layers >= K of both towers runs on a stream of its
+  own, behind the gradient norm, and the NEXT forward waits for it in front of layer K (``functional.LATE_WEIGHTS``): the HBM-bound
+  optimizer pass (4.5 GB at ViT-B/16 + text tower, 0.78 ms) overlaps the MFMA-bound first layers instead of standing between two
+  steps.  Same kernel, same arguments, same results; readers of those parameters outside a model forward call
+  ``functional.join_late_weights()`` (``VidCLIP.state_dict`` and ``utils.load_save`` do).
 
 There is no eager fallback: without the HIP library the step raises.
 """
@@ -35,6 +40,24 @@ class AdamW(Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         self.last_grad_norm = None      # device fp32 scalar after a clipped step
         self._plan = None
+        self._late = None               # (ids of the late parameters, first late layer) -- overlap_next_forward()
+        self._late_stream = None
+
+    def overlap_next_forward(self, model, first_late_layer=2):
+        """Run the update of ``encoder.layers[first_late_layer:]`` of the model's towers on a side stream (see the module docstring).
+        ``first_late_layer=None`` switches it off."""
+        self._plan = None
+        if first_late_layer is None:
+            self._late = None
+            return self
+        ids = set()
+        for m in model.modules():
+            layers = getattr(m, "layers", None)
+            if isinstance(layers, torch.nn.ModuleList) and type(m).__name__ == "CLIPEncoder":
+                for layer in layers[first_late_layer:]:
+                    ids.update(id(p) for p in layer.parameters())
+        self._late = (frozenset(ids), int(first_late_layer)) if ids else None
+        return self
 
     # ------------------------------------------------------------------------------------------ planning
     def _active(self):
@@ -61,9 +84,11 @@ class AdamW(Optimizer):
             if st["exp_avg"].dtype != torch.float32 or not st["exp_avg"].is_contiguous() or st["exp_avg"].device != dev:
                 raise TypeError("xpretrain_amd AdamW: optimizer state must be contiguous fp32 tensors on the parameter's device")
             tensors.append((gi, p, st))
+        late_ids = self._late[0] if self._late else frozenset()
+        sets = [[t for t in tensors if id(t[1]) not in late_ids], [t for t in tensors if id(t[1]) in late_ids]]
+        parts = [(tl[i0:i0 + L.XP_OPT_MAX_TENSORS], k == 1) for k, tl in enumerate(sets) for i0 in range(0, len(tl), L.XP_OPT_MAX_TENSORS)]
         n_total_chunks = 0
-        for i0 in range(0, len(tensors), L.XP_OPT_MAX_TENSORS):
-            part = tensors[i0:i0 + L.XP_OPT_MAX_TENSORS]
+        for part, late in parts:
             tab = (L.XpAdamTensor * len(part))()
             cmap = []
             for j, (gi, p, st) in enumerate(part):
@@ -77,7 +102,7 @@ class AdamW(Optimizer):
             raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
             launches.append(dict(part=part, table=raw.to(dev), n=len(part),
                                  chunk_map=torch.tensor(cmap, dtype=torch.int32).to(dev),
-                                 n_chunks=len(cmap) // 2, chunk_base=n_total_chunks,
+                                 n_chunks=len(cmap) // 2, chunk_base=n_total_chunks, late=late,
                                  grads=(C.c_void_p * len(part))(), grp=(C.c_uint8 * len(part))()))
             n_total_chunks += len(cmap) // 2
         return dict(key=self._plan_key(act, cache), sig=[(gi, p, p.data_ptr(), self.state[p], self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
@@ -91,7 +116,7 @@ class AdamW(Optimizer):
         def moments(p):
             st = self.state.get(p)
             return (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) if st and "exp_avg" in st else (0, 0)
-        return (tuple((gi, id(p), p.data_ptr()) + moments(p) for gi, p in act), cache.structure_version)
+        return (tuple((gi, id(p), p.data_ptr()) + moments(p) for gi, p in act), cache.structure_version, self._late)
 
     # ------------------------------------------------------------------------------------------ step
     @torch.no_grad()
@@ -153,17 +178,52 @@ class AdamW(Optimizer):
                 L.check(lib.xp_grad_sqnorm_partials(la["table"].data_ptr(), la["chunk_map"].data_ptr(), la["n_chunks"],
                                                     la["grads"], la["n"], part.data_ptr(), stream),
                         "xp_grad_sqnorm_partials")
-        for la in plan["launches"]:
+        from .. import functional as XF
+        XF.join_late_weights()                      # (a previous step's late update nobody waited for: two steps without a forward)
+        late = [la for la in plan["launches"] if la["late"]]
+        overlap = bool(late) and not torch.cuda.is_current_stream_capturing()
+        dev = plan["norm"].device
+
+        def run(la, st):
             L.check(lib.xp_adamw_step(la["table"].data_ptr(), la["chunk_map"].data_ptr(), la["n_chunks"], la["grads"],
                                       la["grp"], la["n"], groups, len(eff),
                                       plan["partials"].data_ptr() if clip else None, plan["n_chunks"] if clip else 0,
                                       float(max_grad_norm) if clip else 0.0,
-                                      plan["norm"].data_ptr() if clip else None, stream), "xp_adamw_step")
+                                      plan["norm"].data_ptr() if clip else None, st), "xp_adamw_step")
+        if overlap:
+            # the late launches first in stream order of THEIR stream: behind everything the main stream has enqueued so far (the
+            # gradients, the norm partials), beside whatever the main stream enqueues next (the early launches, the next forward)
+            if self._late_stream is None or self._late_stream.device != dev:
+                self._late_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._late_stream.wait_stream(main)
+            with torch.cuda.stream(self._late_stream):
+                seen = set()
+                for la in late:
+                    for _, p, _ in la["part"]:          # the caching allocator must not hand a freed gradient to the next forward
+                        sp = p.grad.untyped_storage().data_ptr()      # while this stream still reads it (zero_grad(set_to_none=True))
+                        if sp not in seen:
+                            seen.add(sp)
+                            p.grad.record_stream(self._late_stream)
+                    run(la, self._late_stream.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(self._late_stream)
+            XF.LATE_WEIGHTS["event"], XF.LATE_WEIGHTS["first_layer"] = ev, self._late[1]
+        for la in plan["launches"]:
+            if not (overlap and la["late"]):
+                run(la, stream)
         self.last_grad_norm = plan["norm"] if clip else None
         self._wrote = plan["entries"]
         return loss
 
+    def state_dict(self):
+        from .. import functional as XF
+        XF.join_late_weights()           # the moments of the late layers may still be in flight on the optimizer's stream
+        return super().state_dict()
+
     def load_state_dict(self, state_dict):
+        from .. import functional as XF
+        XF.join_late_weights()
         super().load_state_dict(state_dict)
         self._plan = None                # the moment tensors were replaced
 
