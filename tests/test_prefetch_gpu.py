@@ -59,3 +59,28 @@ def test_prefetch_on_the_text_stream_copies_behind_the_text_tower():
     with pytest.raises(StopIteration):
         next(it)
     CLIPModel._deferred_text_work.clear()
+
+
+def test_abandoned_iteration_does_not_leak_its_deferred_copy_into_the_next():
+    """with stream='text' an iteration left early (a ``break`` without a following CLIPModel.forward) kept its armed closure --
+    bound to the OLD iterator -- in the loader and in CLIPModel._deferred_text_work; the next iteration's first next() then ran it and
+    replaced the new epoch's first batch by one of the abandoned iterator.  The closure is withdrawn when an iteration starts or ends."""
+    from xpretrain_amd.modeling.CLIP_ViP import CLIPModel
+    from xpretrain_amd.utils.prefetch import PrefetchLoader
+    host = [{"x": torch.full((4,), float(i))} for i in range(5)]
+    CLIPModel._deferred_text_work.clear()
+    loader = PrefetchLoader(host, stream="text")
+    for b in loader:                       # an eval loop that bails out after one batch
+        assert float(b["x"][0]) == 0.0
+        break
+    assert not CLIPModel._deferred_text_work and loader._armed is None       # (generator closed: finally ran)
+    it = iter(loader)
+    first = next(it)                       # abandoned WITHOUT closing the generator: the stale closure is still registered ...
+    stale = list(CLIPModel._deferred_text_work)
+    assert len(stale) == 1
+    got = [float(b["x"][0]) for b in loader]                                # ... and a new iteration must not see it
+    assert got == [0.0, 1.0, 2.0, 3.0, 4.0]
+    stale[0]()                             # a late run of the abandoned closure (a model forward holding it) is a no-op
+    assert float(first["x"][0]) == 0.0
+    assert [float(b["x"][0]) for b in loader] == [0.0, 1.0, 2.0, 3.0, 4.0]
+    CLIPModel._deferred_text_work.clear()

@@ -156,6 +156,7 @@ extern "C" int xp_encoder_layer_fwd(const XpLayerFwd* a, void* st) {
   // pre = h2 W1^T + b1 ; act = quick_gelu(pre)
   g = gemm_desc(a->h2, a->W1, a->act, rows, Dff, D, dt);
   g.epilogue = XP_EPI_BIAS_GELU; g.bias = a->b1; g.aux = a->pre;
+  if (xp_debug_flag("fc1_no_pre")) g.aux = nullptr;      // measurement only (tools/fc1_one_output.py): the backward then reads garbage
   if ((rc = xp_gemm(&g, st))) return rc;
   // x3 = x2 + act W2^T + b2
   g = gemm_desc(a->act, a->W2, a->x3, rows, D, Dff, dt);

@@ -580,11 +580,13 @@ class CLIPModel(CLIPPreTrainedModel):
                                                position_ids=position_ids, output_attentions=output_attentions,
                                                output_hidden_states=output_hidden_states)
                 text_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(text_outputs["pooler_output"], self.text_projection.weight))
+                text_done = torch.cuda.Event()
+                text_done.record(side)                          # the join below waits for the TOWER, not for what is queued behind it
                 CLIPModel.run_deferred_text_stream_work()       # (e.g. the loader's copy of the NEXT batch: behind the text tower's forward)
             vision_outputs = self.vision_model(pixel_values=pixel_values, output_attentions=output_attentions,
                                                output_hidden_states=output_hidden_states)
             image_embeds = XF.L2NormFn.apply(XF.ProjectionFn.apply(vision_outputs["pooler_output"], self.visual_projection.weight))
-            main.wait_stream(side)
+            main.wait_event(text_done)
             text_embeds.record_stream(main)
             return self._finish(image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict,
                                 output_hidden_states)

@@ -58,13 +58,25 @@ class PrefetchLoader(object):
                 self.stream = torch.cuda.Stream()
         return self.stream
 
+    def _disarm(self):
+        """Drop a deferred copy nobody ran (an iteration abandoned without a following CLIPModel.forward: a ``break`` or an exception in
+        a loop that only calls forward_video / forward_text).  Left armed, its closure -- bound to the OLD iterator -- would run inside
+        the next iteration's first ``next()`` and replace that iteration's first batch."""
+        armed, self._armed = self._armed, None
+        if armed is not None and self._cancel is not None:
+            self._cancel(armed)
+
     def __iter__(self):
+        self._disarm()
         loader_it = iter(self.loader)
-        self.preload(loader_it)
-        batch = self.next(loader_it)
-        while batch is not None:
-            yield batch
+        try:
+            self.preload(loader_it)
             batch = self.next(loader_it)
+            while batch is not None:
+                yield batch
+                batch = self.next(loader_it)
+        finally:
+            self._disarm()
 
     def __len__(self):
         return len(self.loader)
@@ -98,7 +110,7 @@ class PrefetchLoader(object):
             record_cuda_stream(batch)
         if self._defer is not None and batch is not None:
             def once():
-                if self._armed is once:
+                if self._armed is once:          # (a closure of an abandoned iteration is no longer the armed one: it does nothing)
                     self._armed = None
                     self.preload(it)
             self._armed = once
