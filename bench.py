@@ -58,6 +58,18 @@ def pmc_traffic(variant):
     return int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), note
 
 
+def pmc_vit_forward():
+    """Aggregate MFMA-busy fraction of the video tower's training-mode forward from the newest kept PMC summary
+    (profiles/r*_pmc_vit_forward.json: one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass over tools/fwd_only.py,
+    summarised by tools/pmc_vit_forward.py).  (fraction | None, note)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_vit_forward.json")))
+    if not files:
+        return None, "no profiles/r*_pmc_vit_forward.json"
+    d = json.load(open(files[-1]))
+    return d.get("mfma_busy_frac"), f"{os.path.basename(files[-1])}: {d.get('note', '')}"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -406,8 +418,12 @@ def main():
     LR, TOTAL_STEPS = 5e-6, 100000
     groups = build_e2e_optimizer_w_lr_mul(list(model.named_parameters()), LR, 0.05, lr_mul=1, lr_mul_prefix="")
     opt = AdamW([g for g in groups if g["params"]], lr=LR, betas=(0.9, 0.98))
-    if a.opt_overlap >= 0 and a.graph != 1:
-        opt.overlap_next_forward(model, a.opt_overlap)
+    # single-process step only: beside a process group's streams the optimizer's own stream is one stream too many (beyond
+    # four the runtime shares hardware queues) -- through a one-rank RCCL group it costs +0.08 ms instead of saving 0.10
+    # (profiles/r06o_in_step_ab_optimizer_overlap_under_forced_collectives.txt)
+    opt_overlap = a.opt_overlap if (a.opt_overlap >= 0 and a.graph != 1 and W == 1 and not forced) else None
+    if opt_overlap is not None:
+        opt.overlap_next_forward(model, opt_overlap)
     sched_step = [1000]      # start past the warmup so the synthetic loss moves
     video, ids, mask = O.synthetic_inputs(a.batch, a.frames, a.res, a.txt_len, seed=4321 + rank)
     batches = None
@@ -570,8 +586,16 @@ def main():
         (k_tf_iso, k_ms_iso), (b_tf, b_ms) = dom["fwd"], dom["bwd"]
         # roofline of the dominant forward kernel: the in-step measurement (isolated launches of the same kernel are kept beside it:
         # back-to-back identical GEMMs run at a lower clock than the same kernel between the step's memory-bound neighbours)
-        k_ms = fc1_in_step_ms if fc1_in_step_ms else k_ms_iso
-        k_tf = 2.0 * rows * 768 * 3072 / (k_ms * 1e-3) / 1e12
+        # Primary: the launch of the SHIPPED step -- the video tower's forward runs as two half-batch chains, so fc1 is a [rows/2] launch
+        # (444 workgroups at cfg #2) that shares the chip with the other chain's kernels; secondary: the full-batch launch of a one-chain
+        # step (the per-kernel quantity of rounds 1-5) and isolated launches.
+        k1_ms = fc1_in_step_ms if fc1_in_step_ms else k_ms_iso
+        k1_tf = 2.0 * rows * 768 * 3072 / (k1_ms * 1e-3) / 1e12
+        shipped = two_chains and fc1_two_chain_ms
+        k_rows = rows // 2 if shipped else rows
+        k_ms = fc1_two_chain_ms if shipped else k1_ms
+        k_tf = 2.0 * k_rows * 768 * 3072 / (k_ms * 1e-3) / 1e12
+        mfma_busy, mfma_note = pmc_vit_forward()
         bw_ms = dw1_in_step_ms if dw1_in_step_ms else b_ms
         bw_tf = 2.0 * rows * 768 * 3072 / (bw_ms * 1e-3) / 1e12
         full = rows == 18848
@@ -591,6 +615,7 @@ def main():
                        "prefetch": ({"loader": "xpretrain_amd.utils.prefetch.PrefetchLoader", "host_frames": a.prefetch_dtype,
                                      "copy_stream": {1: "own", 2: "text tower's", 3: "auto"}[a.prefetch]} if a.prefetch else None),
                        "video_forward_chains": 2 if two_chains else 1,
+                       "optimizer_overlaps_next_forward_from_layer": opt_overlap,
                        "second_chain_stream": XF.second_chain_stream_mode() if two_chains else None,
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager", "profile_run": bool(a.profile_run)},
             "step_tflops_per_gpu": round(step_flops / (dt / a.steps) / 1e12, 1),
@@ -605,32 +630,38 @@ def main():
             "vit_forward_note": "vit_forward_ms = inference mode (torch.no_grad: no pre-activation kept); the fraction of peak is "
                                 "quoted on vit_forward_train_mode_ms, the kernels the benchmark step runs",
             # dominant forward kernel; algorithmic bytes = A + W + two bf16 outputs
-            "roofline": {"bound": "mfma", "kernel": f"gemm256_kernel<NT> (256x256 tiles, the kernel the training step runs) fc1 +bias+quick_gelu, two bf16 outputs [{rows}x768]x[768x3072]",
+            "roofline": {"bound": "mfma", "kernel": f"gemm256_kernel<NT> (256x256 tiles, the kernel the training step runs) fc1 +bias+quick_gelu, two bf16 outputs [{k_rows}x768]x[768x3072]",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(k_ms, 4),
-                         "kernel_ms_source": ("median of the kernel's launches inside 3 training steps after the timed region, run as ONE forward chain "
-                                              "(HIP events on the launch stream, xp_debug_gemm_timer)" if fc1_in_step_ms else "30 isolated launches (HIP events)"),
-                         # NOT the shipped configuration: the timed step runs the video tower as two half-batch chains, whose launches share the
-                         # chip (next field); one full-batch launch per layer is the per-kernel quantity a roofline is defined on
-                         "measured_in": "one-chain steps (XPRETRAIN_FWD_SPLIT=0)" if fc1_in_step_ms else "isolated launches",
-                         "rocprof_check": "profiles/r05z_kernel_by_grid.txt: gemm256_kernel<false, false>, 888 workgroups (tools/kernel_by_grid.py)",
-                         # the shipped step: two half-batch chains; a [rows/2] launch beside the other chain's kernels (a shared-chip duration)
-                         "kernel_ms_half_batch_launch_beside_the_other_chain": None if fc1_two_chain_ms is None else round(fc1_two_chain_ms, 4),
+                         "kernel_ms_source": ("median of the kernel's launches inside 3 ordinary training steps after the timed region (HIP events on the "
+                                              "launch stream, xp_debug_gemm_timer)" if (shipped or fc1_in_step_ms) else "30 isolated launches (HIP events)"),
+                         # the shipped mode: a half-batch launch beside the OTHER chain's kernels -- a shared-chip duration, so `frac` is the
+                         # rate of one of two concurrent chains, not of the chip; `one_chain` below is the per-kernel quantity of earlier rounds
+                         "measured_in": "two-chain steps" if shipped else ("one-chain steps (XPRETRAIN_FWD_SPLIT=0)" if fc1_in_step_ms else "isolated launches"),
+                         "workgroups": (k_rows + 255) // 256 * 12, "concurrent_chains": 2 if shipped else 1,
+                         "rocprof_check": "profiles/r06z_kernel_by_grid.txt: gemm256_kernel<false, false>, 444 workgroups (two-chain steps) / 888 (one-chain)",
+                         "one_chain": {"kernel_ms": round(k1_ms, 4), "achieved": round(k1_tf, 1), "frac": round(k1_tf / PEAK_BF16_TFLOPS, 4),
+                                       "measured_in": "one-chain steps (XPRETRAIN_FWD_SPLIT=0): the full-batch launch alone on the chip apart from the text tower" if fc1_in_step_ms else "isolated launches"},
                          "kernel_ms_isolated": round(k_ms_iso, 4), "frac_isolated": round(k_tf_iso / PEAK_BF16_TFLOPS, 4),
-                         "traffic": tr_f, "traffic_unit": "bytes/launch", "traffic_source": note_f,
-                         "algorithmic_bytes": (rows * 768 + 3072 * 768 + 2 * rows * 3072) * 2},
+                         # every kernel of the video tower's training-mode forward: matrix-core busy cycles / (SIMDs x elapsed cycles)
+                         "vit_forward_mfma_busy_frac": mfma_busy, "vit_forward_mfma_busy_source": mfma_note,
+                         "traffic": tr_f, "traffic_unit": "bytes/launch (full-batch launch)", "traffic_source": note_f,
+                         "algorithmic_bytes": (k_rows * 768 + 3072 * 768 + 2 * k_rows * 3072) * 2},
             # dominant backward kernel (incl. its split-K reduce); algorithmic bytes = dpre + h2 + fp32 dW
+            # `frac` / `kernel_ms`: 30 isolated launches INCLUDING the split-K reduce (the quantity of rounds 1-4, comparable across rounds);
+            # `in_step_gemm_only`: the GEMM kernel alone where it runs (the reduce -- 35 us in the step, profiles/r06z_kernel_by_grid.txt -- is
+            # not inside the timer's bracket)
             "roofline_bwd": {"bound": "mfma", "kernel": f"gemm256_kernel<SS> dW1 = dpre^T.h2 [3072x{rows}]x[{rows}x768] split-K {dw1_split} into fp32 slabs",
-                             "achieved": round(bw_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(bw_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(bw_ms, 4),
-                             "kernel_ms_source": ("in-step: median of the GEMM kernel's launches inside 3 training steps (HIP events on the weight-gradient "
-                                                  "stream it is launched on, xp_debug_gemm_timer); it runs beside the dX chain of the main stream, so the "
-                                                  "duration is a shared-chip one" if dw1_in_step_ms else "30 isolated launches incl. the reduce"),
-                             "kernel_ms_isolated_with_reduce": round(b_ms, 4), "frac_isolated_with_reduce": round(b_tf / PEAK_BF16_TFLOPS, 4),
-                             # the split-K planning fills at most 112 CUs here on purpose (csrc/gemm.hip::XP_SPLITK_FILL_SLACK: the launch runs beside the dX
-                             # chain and every split is an fp32 slab written and read again) -- `frac` is a whole-chip rate of a launch that holds
-                             # `workgroups` of the 256 CUs; `frac_of_held_cus` is the same time against the peak of the CUs it occupies
-                             "workgroups": 36 * dw1_split, "frac_of_held_cus": round(bw_tf / PEAK_BF16_TFLOPS * 256.0 / min(256, 36 * dw1_split), 4),
+                             "achieved": round(b_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(b_tf / PEAK_BF16_TFLOPS, 4), "kernel_ms": round(b_ms, 4),
+                             "kernel_ms_source": "30 isolated launches incl. the split-K reduce",
+                             "in_step_gemm_only": None if not dw1_in_step_ms else {
+                                 "kernel_ms": round(bw_ms, 4), "achieved": round(bw_tf, 1), "frac": round(bw_tf / PEAK_BF16_TFLOPS, 4),
+                                 "source": "median of the GEMM kernel's launches inside 3 training steps (HIP events on the weight-gradient stream it is "
+                                           "launched on, xp_debug_gemm_timer); it runs beside the dX chain of the main stream: a shared-chip duration",
+                                 # the split-K planning fills at most 112 CUs here on purpose (csrc/gemm.hip::XP_SPLITK_FILL_SLACK): `frac` is a
+                                 # whole-chip rate of a launch that holds `workgroups` of the 256 CUs
+                                 "workgroups": 36 * dw1_split, "frac_of_held_cus": round(bw_tf / PEAK_BF16_TFLOPS * 256.0 / min(256, 36 * dw1_split), 4)},
                              "traffic": tr_b, "traffic_unit": "bytes/launch (GEMM kernel only)", "traffic_source": note_b,
                              "algorithmic_bytes": (rows * 3072 + rows * 768) * 2 + 3072 * 768 * 4},
         }

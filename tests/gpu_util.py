@@ -66,7 +66,8 @@ def bf16_round(t: torch.Tensor) -> torch.Tensor:
 TOL = {
     "features_abs": 2e-2,          # north_star's bound; only the tiny widened-weight fixture needs more than 2e-3 (5.1e-3 measured)
     "features_abs_full": 2e-3,     # |vis - ref|, |txt - ref| at every real architecture (cfg1..4, b8): vis <= 6.8e-4, txt <= 1.1e-3
-    "cos_abs": 1.5e-3,             # |vis.txt^T - ref|: <= 6.3e-4
+    "cos_abs": 1e-3,               # |vis.txt^T - ref|: <= 6.7e-4 (round 6, every full-size case); x e^4.6 it is the logit deviation, which
+                                   # tests/test_fullsize_parity_gpu.py also holds against the reference's OWN bf16 autocast deviation
     "loss_rel": 2e-2,              # |loss - fp32 reference| / |loss|, north_star's number: <= 9.8e-3
     "loss_ref_abs": 3e-2,          # absolute, every batch-2 case: <= 2.0e-2 on the fixtures; over six input draws per shape the
                                    # population maximum is 2.5e-2 (tools/loss_seed_study.py, profiles/r04b_loss_seed_study.txt): an
@@ -78,14 +79,18 @@ TOL = {
     "hidden_emu_e2e": 3e-2,        # free-running 12-layer trajectories vs the emulation: 2.1e-2
     "hidden_ref": 3.5e-2,          # hidden-state rows vs reference fp32: 2.3e-2
     "grad_emu": 2e-2,              # teacher-forced: dx and every video-tower parameter gradient: <= 1.7e-2 (batch 8: 1.2e-2)
-    "grad_emu_small": 1e-1,        # teacher-forced text-tower parameter gradients: <= 6.8e-2 (attention block; formulation scatter 4.4-5.5e-2
+    "grad_emu_small": 8e-2,        # teacher-forced text-tower parameter gradients: <= 6.7e-2 (attention block; formulation scatter 4.4-5.5e-2
                                    # measured on the CPU, see above), <= 1.8e-2 outside it
     "grad_ref_2d": 7.5e-2,         # weight gradients vs reference fp32, free-running: <= 5.0e-2
-    "grad_ref_1d": 2.5e-1,         # 1-D gradients vs reference fp32, free-running: <= 1.7e-1 at batch 2, 9.2e-2 at batch 8
+    "grad_ref_1d": 2e-1,           # 1-D gradients vs reference fp32, free-running: <= 1.55e-1 at batch 2, 1.15e-1 at batch 8 (round 6)
 }
 # the same table at the bench batch (tests/golden/full_cfg2_b8.pt): better-conditioned sums (256 text rows / 18848 video rows)
 TOL_B8 = {"loss_ref_abs": 1.5e-2,          # 1.6e-3 measured at 8 pairs (0.03 %); the bound leaves room for the ~1e-2 scatter between builds
-          "grad_ref_1d": 1.4e-1, "grad_ref_2d": 7e-2}
+          "grad_ref_1d": 1.4e-1, "grad_ref_2d": 7e-2}          # (1-D: 1.15e-1 measured with the fused attention backward, 9.2e-2 before)
+# the raw logits against the reference's own reduced-precision run: |d logits| of this build (vs the reference's fp32 run) may be at
+# most this multiple of what the reference's torch.autocast(bfloat16) run shows against the same fp32 run (`ref_bf16.dlogits` in the
+# fixtures: 3.0e-2 / 1.0e-1 / 3.4e-2 / 5.8e-2; this build: 3.4e-2 / 6.7e-2 / 6.0e-2 / 4.9e-2 -- the same order, not always below)
+LOGITS_VS_REFERENCE_BF16 = 2.0
 
 
 def loss_gate(loss: float, ref: float, abs_tol: float, rel_tol: float = None) -> bool:

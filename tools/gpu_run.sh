@@ -11,6 +11,8 @@
 #   profile [bench.py args]        rocprofv3 --kernel-trace --stats of bench.py: per-kernel stats + one row per (kernel, grid)
 #                                                                                     -> gpurun_out/<tag>/{kernel_stats.csv,kernel_by_grid.txt,bench_under_rocprof.json}
 #   pmc                            PMC passes of the 256-wide GEMM family (tools/pmc_gemm256.sh)  -> gpurun_out/<tag>_pmc_gemm256.json
+#   pmcfwd                         MFMA-busy fraction of the video tower's training-mode forward  -> gpurun_out/<tag>_pmc_vit_forward.json
+#   pmcattn                        SQ / HBM counters of the attention kernels                    -> gpurun_out/<tag>/pmc_sq_attention.txt
 #   timeline [shapes]              per-tile timeline of single GEMM launches (tools/gemm_timeline.py) -> gpurun_out/<tag>/timeline.txt
 #   vendor  [args]                 in-step calibration against the vendor library (tools/vendor_instep.py) -> gpurun_out/<tag>/vendor_instep.txt
 set -u
@@ -42,6 +44,17 @@ print('bench', d['value'], 'pairs/s', d['ms_per_step'], 'ms/step; vit fwd', d['v
 import json; d=json.load(open('$O/bench_under_rocprof.json')); print('the same run: roofline.kernel_ms (HIP events, median of the in-step fc1 launches) =', d['roofline']['kernel_ms'], 'ms;', d['ms_per_step'], 'ms/step under the profiler')" ;;
   pmc)
     bash tools/pmc_gemm256.sh $TAG > $O/pmc.log 2>&1; tail -1 $O/pmc.log | cut -c1-300 ;;
+  pmcfwd)
+    # aggregate MFMA-busy fraction of the video tower's training-mode forward (one PMC pass, tools/pmc_vit_forward.py)
+    rm -rf /tmp/pmcfwd_$TAG
+    ( cd $R && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcfwd_$TAG -o f -- python tools/fwd_only.py 5 12 224 train ) > $O/pmcfwd.log 2>&1
+    python3 tools/pmc_vit_forward.py $(find /tmp/pmcfwd_$TAG -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_pmc_vit_forward.json $TAG | head -12 ;;
+  pmcattn)
+    # SQ counters of the attention kernels (forward persistent kernel + fused backward), two passes -> gpurun_out/<tag>/pmc_sq_attention.txt
+    { bash tools/pmc.sh ${TAG}_pa1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" tools/attn_bwd_probe.py 5 fused colsum;
+      bash tools/pmc.sh ${TAG}_pa2 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" tools/attn_bwd_probe.py 5 fused colsum;
+      bash tools/pmc.sh ${TAG}_pa3 "FETCH_SIZE" tools/attn_bwd_probe.py 5 fused colsum; bash tools/pmc.sh ${TAG}_pa4 "WRITE_SIZE" tools/attn_bwd_probe.py 5 fused colsum; } 2>&1 | grep -v "^W20\|amdgpu.ids" | grep -A10 "attn_bwd5_kernel\|attn_fwd3_kernel" > $O/pmc_sq_attention.txt
+    head -30 $O/pmc_sq_attention.txt ;;
   timeline)
     timeout 300 python tools/gemm_timeline.py "$@" 2>&1 | grep -v amdgpu.ids | cut -c1-1500 | tee $O/timeline.txt ;;
   vendor)

@@ -815,7 +815,12 @@ static const bool g_fill_env = [] {
 }();
 static int32_t auto_split_fill(const XpGemmDesc* d, int64_t fill);
 extern "C" int32_t xp_gemm_auto_split(const XpGemmDesc* d) { return auto_split_fill(d, g_fill[0]); }
-extern "C" int32_t xp_gemm_auto_split_slack(const XpGemmDesc* d) { return auto_split_fill(d, g_fill[1]); }
+extern "C" int32_t xp_gemm_auto_split_slack(const XpGemmDesc* d) {
+  // never MORE slabs than the general plan: when the 256-wide family refuses the smaller slack split, auto_split_fill falls into the
+  // 128-family branch, whose answer does not know the fill
+  const int32_t s = auto_split_fill(d, g_fill[1]), g = auto_split_fill(d, g_fill[0]);
+  return s < g ? s : g;
+}
 
 static int32_t auto_split_fill(const XpGemmDesc* d, int64_t fill) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 1;

@@ -387,7 +387,7 @@ bool xp_gemm256_wanted(const XpGemmDesc* d, int split) {
 // (profiles/r05k_in_step_ab_l2_column_groups.txt); fabric fetch of fc1: profiles/r05l_pmc_gemm256.json.
 int xp_gemm256_group_n(const XpGemmDesc* d, int tiles_n) {
   int groups = 1;
-  const int64_t wbytes = (int64_t)tiles_n * TN * d->K * 2;
+  const int64_t wbytes = (int64_t)tiles_n * TN * d->K * (d->in_dtype == XP_BF16 ? 2 : 4);      // (element size of the operands: ADVICE r5)
   while (groups < 4 && wbytes / groups > (int64_t)3600 * 1024 && tiles_n / (groups * 2) >= 4) groups *= 2;
   return (int)cdiv(tiles_n, groups);
 }

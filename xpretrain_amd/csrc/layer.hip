@@ -40,6 +40,7 @@ int wgrad(const void* dy, const void* x, float* dw, int64_t rows, int64_t n_out,
   d.C = slabs; d.split_k = split;
   int rc = xp_gemm(&d, st);
   if (rc) return rc;
+  if (xp_debug_flag("skip_splitk_reduce")) return XP_OK;      // measurement only (wrong gradients): what the four reduces of a layer cost the step
   return xp_splitk_reduce(slabs, dw, n_out * n_in, split, 0, st);
 }
 

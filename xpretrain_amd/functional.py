@@ -148,7 +148,7 @@ _SPLITS = {}
 def _split_for(n_out: int, n_in: int, rows: int, dtype: torch.dtype, a_remap, slack: bool = False) -> int:
     """split-K factor for the weight-gradient GEMMs (kernel-family aware, decided by the library; memoised).  ``slack``: a launch
     nothing waits for soon (the first three dW GEMMs of a layer's backward, as csrc/layer.hip issues them): fewer, longer slabs."""
-    key = (n_out, n_in, rows, dtype, a_remap, slack)
+    key = (n_out, n_in, rows, dtype, a_remap, slack, int(L.lib().xp_get_cu_budget()))      # (the CU budget is part of the plan: ADVICE r5)
     s = _SPLITS.get(key)
     if s is None:
         s = _SPLITS[key] = H.gemm_auto_split(n_out, n_in, rows, dtype, lda=n_out, ldb=n_in, a_remap=a_remap, slack=slack)
