@@ -11,6 +11,11 @@
  *   - plain pointers + sizes; no torch types.  Every pointer is a DEVICE pointer unless named host_*.
  *   - never allocates, never synchronises, never owns memory; launches only on `stream`
  *     (a hipStream_t passed as void*); re-entrant (forward thread + autograd thread).
+ *     The three deviations an integrator must know, all documented at the entry point concerned: (1) xp_encoder_layer_bwd runs a
+ *     layer's weight-gradient GEMMs on ONE library-owned stream per device (xp_side_stream(), created on first use, ordered against
+ *     `stream` by library-owned events, joined before the call returns); (2) xp_set_cu_budget() is process-global planning state;
+ *     (3) xp_attn_bwd / xp_attn_bwd2 enqueue one 4-byte hipMemsetAsync on `stream` (the fused backward's problem counter, inside the
+ *     caller's workspace).
  *   - returns 0 on success, a negative XP_ERR_* otherwise; xp_last_error() gives the thread-local message.
  *   - `dtype`: element type of activations / GEMM operands (XP_BF16 or XP_F32).  Parameters that are read
  *     directly from the fp32 master copy (biases, LayerNorm affine, embedding tables) are always float.
@@ -210,7 +215,10 @@ int xp_attn_fwd(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* s
                 int64_t M, int64_t N, int64_t L, int32_t dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
 /* dqkv[B,S,3,H,64] (same layout as qkv; dq already multiplied by q_scale so it is the gradient of the
- * un-scaled projection output). */
+ * un-scaled projection output).  PROXY problems that fit one LDS group (M + L <= 208, M <= 16, no padding mask: 224^2 frames at patch
+ * 16, any frame count) run as ONE persistent launch for dQ, dK and dV (attn_bwd5_kernel, round 6); its workgroups take problems from
+ * a 4-byte device counter at the end of `workspace`, which this call resets with hipMemsetAsync on `stream` (the one operation of the
+ * library besides kernel launches, event records and waits).  Everything else runs the dQ kernel, then the dK/dV kernel. */
 int xp_attn_bwd(const void* qkv, int64_t ldqkv, const void* out, const void* dout, int64_t ldo,
                 const float* stats, const int64_t* pad_mask, void* dqkv, float q_scale,
                 int32_t mode, int64_t B, int64_t H, int64_t S, int64_t M, int64_t N, int64_t L, int32_t dtype,

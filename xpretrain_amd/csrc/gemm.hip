@@ -795,13 +795,16 @@ extern "C" int32_t xp_get_cu_budget(void) { return g_cu_budget; }
 // Split-K launches (the weight gradients) do not fill the chip: they run on the weight-gradient stream BESIDE the dX chain, which takes
 // whatever CUs they leave, and every split costs an fp32 slab written and read again -- at a fill of 256 (splits 7 / 9 / 27 for the
 // 36- / 27- / 9-tile outputs of ViT-B) the slabs of one layer are 260 MB each way, 6.2 GB per step, more than the optimizer moves.
-//   XP_SPLITK_FILL        176 CUs: the general answer (xp_gemm_auto_split): 4 / 6 / 19
+//   XP_SPLITK_FILL        144 CUs (176 in round 5): the general answer (xp_gemm_auto_split): 4 / 5 / 16
 //   XP_SPLITK_FILL_SLACK  112 CUs: launches nothing waits for soon (xp_gemm_auto_split_slack: fc2, fc1, out_proj of a layer): 3 / - / 12
 // Whole step, interleaved: fill 256 -> 176 for all four: 15.55 -> 15.14 ms (208: 15.35, 144: 15.31, 128: 15.29;
 // profiles/r05s_in_step_ab_splitk_fill.txt); per-GEMM search around it (profiles/r05x_in_step_ab_splitk_per_gemm.txt): the q/k/v
 // gradient -- the last of the layer, the one the join waits for -- has a sharp optimum at 6 (4: +0.27 ms, 9: +0.24), fc1 / fc2 want 3
 // (4: +0.10, 5: +0.20), out_proj is flat between 12 and 19 (27: +0.08): 4/6/19 -> 3/6/12 is another -0.16 ms.
-constexpr int64_t XP_SPLITK_FILL = 176, XP_SPLITK_FILL_SLACK = 112;
+// Round 6 (the fused attention backward shortened the dX chain, the balance of the two streams moved): larger fills lose (208 / 240:
+// +0.02 ... +0.15 ms, profiles/r06g_*), the q/k/v gradient at 5 slabs instead of 6 (fill 144) is -0.10 ms, 4 (fill 112) level again
+// (profiles/r06r_in_step_ab_splitk_fill_smaller.txt): 3 / 5 / 12.
+constexpr int64_t XP_SPLITK_FILL = 144, XP_SPLITK_FILL_SLACK = 112;
 // XPRETRAIN_SPLITK_FILL=general[xslack] (e.g. 208x144): the A/B switch of the two fills (tools/instep_ab.py)
 static int64_t g_fill[2] = {XP_SPLITK_FILL, XP_SPLITK_FILL_SLACK};
 static const bool g_fill_env = [] {

@@ -301,7 +301,8 @@ extern "C" int xp_encoder_layer_bwd(const XpLayerBwd* a, void* st) {
     XP_REQUIRE(xp_reduce_rows_batch_workspace_bytes(df.segs, df.n) <= p.red, "xp_encoder_layer_bwd: reduce scratch too small");
     if ((rc = xp_reduce_rows_batch(df.segs, df.n, red_ws, p.red, st))) return rc;
   }
-  if (wsd) {      // join: the weight gradients (and every workspace the side stream read) belong to the main stream again
+  if (wsd && !xp_debug_flag("no_wgrad_join")) {      // join: the weight gradients (and every workspace the side stream read) belong to the main stream again
+    // (XPRETRAIN_DEBUG=no_wgrad_join: measurement only -- races on the shared workspace -- what a lazy join could be worth at most)
     if (hipEventRecord(wsd->done, wsd->side) != hipSuccess || hipStreamWaitEvent(mst, wsd->done, 0) != hipSuccess) {
       xp_set_error("xp_encoder_layer_bwd: joining the weight-gradient stream failed");
       return XP_ERR_LAUNCH;
