@@ -14,6 +14,7 @@
 #   pmcfwd                         MFMA-busy fraction of the video tower's training-mode forward  -> gpurun_out/<tag>_pmc_vit_forward.json
 #   pmcattn                        SQ / HBM counters of the attention kernels                    -> gpurun_out/<tag>/pmc_sq_attention.txt
 #   timeline [shapes]              per-tile timeline of single GEMM launches (tools/gemm_timeline.py) -> gpurun_out/<tag>/timeline.txt
+#   steptl  [args]                one steady-state step as a per-kernel timeline (tools/step_timeline.py)  -> gpurun_out/<tag>/step_timeline.txt
 #   vendor  [args]                 in-step calibration against the vendor library (tools/vendor_instep.py) -> gpurun_out/<tag>/vendor_instep.txt
 set -u
 TAG=${1:?tag}; TASK=${2:?task}; shift 2
@@ -57,6 +58,13 @@ import json; d=json.load(open('$O/bench_under_rocprof.json')); print('the same r
     head -30 $O/pmc_sq_attention.txt ;;
   timeline)
     timeout 300 python tools/gemm_timeline.py "$@" 2>&1 | grep -v amdgpu.ids | cut -c1-1500 | tee $O/timeline.txt ;;
+  steptl)
+    # one steady-state step as a per-kernel timeline (tools/step_timeline.py) -> gpurun_out/<tag>/step_timeline.txt (+ the raw trace, gzipped)
+    rm -rf /tmp/tl_$TAG
+    timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$TAG -o t -- python tools/step_only.py 8 > $O/steptl.log 2>&1
+    TR=$(find /tmp/tl_$TAG -name "*kernel_trace.csv" | head -1)
+    python3 tools/step_timeline.py $TR "$@" > $O/step_timeline.txt; gzip -c $TR > $O/kernel_trace.csv.gz
+    head -1 $O/step_timeline.txt; tail -1 $O/step_timeline.txt; tail -1 $O/steptl.log ;;
   vendor)
     timeout 900 python tools/vendor_instep.py --out $O/vendor_instep.txt "$@" 2>&1 | grep -v amdgpu.ids | tail -48 ;;
   *) echo "unknown task $TASK"; exit 2 ;;

@@ -60,13 +60,17 @@ __global__ __launch_bounds__(NT) void sqnorm_partials_kernel(const XpAdamTensor*
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// One element.  Every rounding point is written out (no compiler-chosen contraction): left to itself hipcc fused  m*b1 + (1-b1)*g  as
+// fma(b1, m, [(1-b1)*g]) in this kernel and as fma(1-b1, g, [b1*m]) in a second update kernel built from the same source
+// (tools/experiments/adamw_confined.diff).  The form is the one adamw_kernel has compiled to since round 2 (tests/golden/optim.pt: 2e-5).
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const XpAdamGroup& h, float coef) {
-  g *= coef;
-  m = m * h.beta1 + (1.0f - h.beta1) * g;
-  v = v * h.beta2 + (1.0f - h.beta2) * g * g;
+#pragma clang fp contract(off)
+  g = g * coef;
+  m = __builtin_fmaf(h.beta1, m, (1.0f - h.beta1) * g);
+  v = __builtin_fmaf(h.beta2, v, g * ((1.0f - h.beta2) * g));
   const float denom = sqrtf(v) + h.eps;
-  p = p - h.step_size * (m / denom);
-  if (h.weight_decay > 0.f) p = p - (h.lr * h.weight_decay) * p;
+  p = __builtin_fmaf(-h.step_size, m / denom, p);
+  if (h.weight_decay > 0.f) p = __builtin_fmaf(-(h.lr * h.weight_decay), p, p);
 }
 
 __global__ __launch_bounds__(NT) void adamw_kernel(const XpAdamTensor* __restrict__ table,
