@@ -429,9 +429,20 @@ def test_forward_as_two_half_batch_chains_is_bit_identical(monkeypatch, shape, s
         assert torch.equal(v0, v1) and torch.equal(l0, l1)
         bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
         assert not bad, bad[:5]
-    with torch.no_grad():               # forward-only passes: one chain (a layer's buffers are freed as the pass goes)
-        f1 = model(video, ids, mask)["vis_features"]
-    assert len(made) == 3 and torch.equal(f1, v0)
+    with torch.no_grad():               # forward-only passes: two chains as well (the split holds every layer's buffers until the join)
+        for rep in range(3):
+            f1 = model(video, ids, mask)["vis_features"]
+            torch.cuda.synchronize()
+            assert len(made) == 4 + rep and torch.equal(f1, v0)
+        monkeypatch.setattr(XF, "FWD_SPLIT", False)
+        f2 = model(video, ids, mask)["vis_features"]
+        assert len(made) == 6 and torch.equal(f2, v0)
+    monkeypatch.setattr(XF, "FWD_SPLIT", True)
+    for p in model.parameters():        # everything frozen under grad mode: no autograd node keeps the buffers -- the split does
+        p.requires_grad_(False)
+    f3 = model(video, ids, mask)["vis_features"]
+    torch.cuda.synchronize()
+    assert len(made) == 7 and torch.equal(f3, v0)
 
 
 def test_inference_forward_gathers_patches_in_the_gemm(monkeypatch):

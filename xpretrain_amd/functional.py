@@ -278,6 +278,7 @@ def join_late_weights():
 # XPRETRAIN_FWD_SPLIT=0: the whole batch as one chain (A/B switch for the two half-batch chains of the video tower's forward)
 FWD_SPLIT = os.environ.get("XPRETRAIN_FWD_SPLIT", "1") != "0"
 FWD_SPLIT_MIN_ROWS = 8192          # below this a half-batch launch no longer fills the chip beside its twin
+FWD_SPLIT_HOLD_BYTES = 48 << 30    # forward-only passes: the most a split may hold until its join (every layer's buffers; 4.2 GB at cfg #2)
 # FWD_SPLIT_STREAM (module attribute; tools set it): which stream the second chain runs on.  "side": the library's weight-gradient stream, idle
 # during the forward (xp_side_stream) -- the step then touches main + text tower + side = three streams, as before the split.  "own":
 # a torch stream of its own.  Same speed on one GPU (15.75 vs 15.75-15.79 ms per step, profiles/r04w_in_step_ab_second_chain_stream.txt);
@@ -313,17 +314,25 @@ class ForwardSplit:
     that does not maintain the shadows; xp_adamw_step writes them itself, so training steps never re-cast): the second chain then waits
     for that cast.  One chain's HBM-bound kernels (LayerNorm, attention, GEMM epilogues) run beside the other's MFMA main loops, and each chain's 111- /
     333- / 444-tile GEMMs fill the CUs the other leaves idle.  The backward sees ordinary full-batch buffers.  Results are bit-identical
-    to the single chain (the same kernels compute every row).  Only while activations are kept (training passes): nothing of a layer is
-    freed before the chains are joined.  Measured: profiles/r04r_split_batch_probe_gemm256_forced.txt (probe),
-    r04s_in_step_ab_forward_two_chains.txt (the step: -0.46 ms)."""
+    to the single chain (the same kernels compute every row).  Nothing of a layer may be freed before the chains are joined: a
+    training pass keeps its activations for the backward anyway; a forward-only pass (torch.no_grad: retrieval, inference) has the
+    split HOLD every layer's buffers until join() (round 6; ~0.46 GB per layer at cfg #2).  Measured: profiles/r04r_split_batch_probe_gemm256_forced.txt
+    (probe), r04s_in_step_ab_forward_two_chains.txt (the step: -0.46 ms)."""
 
     def __init__(self, device):
         self.stream = _second_chain_stream(device)
         self.main = torch.cuda.current_stream(device)
         self.stream.wait_stream(self.main)          # fork: everything the tower's input depends on
+        self.held = []
+
+    def hold(self, *tensors):
+        """buffers the second chain reads or writes: alive until the chains are joined (the caching allocator knows only the stream
+        that allocated them, and without an autograd node a layer's input and arena die when the next layer returns)"""
+        self.held.extend(t for t in tensors if t is not None)
 
     def join(self):
         self.main.wait_stream(self.stream)
+        self.held.clear()       # (freed on the main stream, behind the join)
 
 
 def _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan, pad_mask, keep_pre=True, side=None,
@@ -495,12 +504,14 @@ class EncoderLayerFn(torch.autograd.Function):
         Wo, W1, W2 = WEIGHTS.get(wo, dt), WEIGHTS.get(w1, dt), WEIGHTS.get(w2, dt)
         if LAYER_CALLS and _native_ok(x, (ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2), (Wqkv, Wo, W1, W2), pad_mask):
             plan = _layer_plan(rows, D, Dff, B, S, heads, size, dt)
-            if split is not None and (not training or size is None or B % 2 or pad_mask is not None):
+            if split is not None and (size is None or B % 2 or pad_mask is not None):
                 split = None
             if split is not None and WEIGHTS.casts != casts0:       # a weight copy was (re)made on this stream just now: the second
                 split.stream.wait_stream(torch.cuda.current_stream())   # chain must not read it before the cast has run
             x3, arena, side_out, side_x2 = _layer_fwd_native(x, ln1_w, ln1_b, Wqkv, bqkv, Wo, bo, ln2_w, ln2_b, W1, b1, W2, b2, plan,
                                                              pad_mask, keep_pre=training, side=side, split=split)
+            if split is not None:
+                split.hold(x, arena, x3, side, side_out, side_x2)
             ctx.save_for_backward(x, arena, ln1_w, ln2_w, Wqkv, Wo, W1, W2, pad_mask, side, side_x2)
             ctx.plan = plan
             if GRAD_SINKS:          # (data-parallel runs only) the layer's parameters in the flat gradient order

@@ -243,14 +243,16 @@ class CLIPEncoder(nn.Module):
         ``collect`` / ``collect_side``: lists that receive every layer output (compute dtype, as ``last_hidden_state``) and its
         fp32 side rows (``output_hidden_states``)."""
         ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
-        # video tower, training pass: two half-batch chains on two streams (functional.ForwardSplit), joined after the last layer.
-        # x.requires_grad: every layer then builds its autograd node and keeps its buffers until backward -- a layer without a node
-        # (everything frozen under grad mode) would free them while the second chain is still using them.
+        # video tower: two half-batch chains on two streams (functional.ForwardSplit), joined after the last layer.  Training passes
+        # keep every layer's buffers in the autograd graph; forward-only passes (and layers without a node: everything frozen under
+        # grad mode) have the split hold them until the join.
         split = None
-        if (XF.FWD_SPLIT and XF.LAYER_CALLS and inputs_size is not None and pad_mask is None and not ckpt and torch.is_grad_enabled()
-                and x.requires_grad and x.is_cuda and B % 2 == 0 and x.shape[0] % 8 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS
+        if (XF.FWD_SPLIT and XF.LAYER_CALLS and inputs_size is not None and pad_mask is None and not ckpt
+                and x.is_cuda and B % 2 == 0 and x.shape[0] % 8 == 0 and x.shape[0] >= XF.FWD_SPLIT_MIN_ROWS
                 and not _has_forward_hooks(self.layers)):     # (a hook would read a layer's output before the second chain wrote it)
-            split = XF.ForwardSplit(x.device)
+            keeps = torch.is_grad_enabled() and x.requires_grad      # (else the split holds ~12x the stream's bytes per layer until the join)
+            if keeps or 12 * len(self.layers) * x.numel() * x.element_size() <= XF.FWD_SPLIT_HOLD_BYTES:
+                split = XF.ForwardSplit(x.device)
         for li, layer in enumerate(self.layers):
             if XF.LATE_WEIGHTS["event"] is not None and x.is_cuda:      # the optimizer's overlapped update of the layers >= K (XF.LATE_WEIGHTS)
                 XF.wait_late_weights(li, *((torch.cuda.current_stream(x.device), split.stream) if split is not None else ()))
