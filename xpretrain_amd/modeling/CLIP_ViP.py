@@ -601,7 +601,7 @@ class CLIPModel(CLIPPreTrainedModel):
         return self._finish(image_embeds, text_embeds, text_outputs, vision_outputs, return_loss, return_dict,
                             output_hidden_states)
 
-    overlap_text_tower = True          # class attribute: False runs the text tower on the caller's stream (A/B: DESIGN.md 6.0)
+    overlap_text_tower = True          # class attribute: False runs the text tower on the caller's stream (A/B: DESIGN_HISTORY.md 6.0)
     _text_streams = {}          # one per device, shared by every model instance (and by utils.prefetch.PrefetchLoader(stream="text"))
 
     @staticmethod
