@@ -66,6 +66,32 @@ def test_reduce_rows_batch_and_deferred_producers():
     for (nrows, width, stride), o, r in zip(cases, outs, refs):
         assert report(f"reduce_batch {nrows}x{width}/{stride}", o, r, 2e-6) <= 2e-6
 
+    # four columns per lane (every segment 16-byte addressable: the encoder layers' segments) against one column per lane
+    # (XPRETRAIN_DEBUG=rows_reduce_scalar; also what a batch with an odd width / pitch falls back to): the same summation order per column
+    import os
+    cases4 = [(1, 64, 64), (64, 200, 256), (65, 768, 768), (589, 3072, 3072), (1024, 768, 1536), (512, 768, 3072), (148, 3072, 3072), (300, 4, 8)]
+    parts = [torch.randn(nrows, stride, device="cuda") for nrows, _, stride in cases4]
+    saved = os.environ.get("XPRETRAIN_DEBUG")
+
+    def run(scalar):
+        os.environ["XPRETRAIN_DEBUG"] = ",".join(filter(None, [saved, "rows_reduce_scalar" if scalar else ""]))
+        try:
+            dd, res = H.DeferredReduce(torch.device("cuda")), []
+            for (nrows, width, stride), part in zip(cases4, parts):
+                out = torch.full((width,), 3.0, device="cuda")
+                dd.add(part, 0, out, nrows, width, stride, accumulate=nrows % 2 == 0)
+                res.append(out)
+            dd.flush()
+            torch.cuda.synchronize()
+            return res
+        finally:
+            if saved is None:
+                os.environ.pop("XPRETRAIN_DEBUG", None)
+            else:
+                os.environ["XPRETRAIN_DEBUG"] = saved
+    for (nrows, width, stride), a, b in zip(cases4, run(False), run(True)):
+        assert torch.equal(a, b), (nrows, width, stride)
+
     for dtype in (torch.bfloat16, torch.float32):
         rows, cols = 2356, 768
         X = torch.randn(rows, cols, device="cuda").to(dtype)

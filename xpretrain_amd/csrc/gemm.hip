@@ -587,6 +587,56 @@ __global__ __launch_bounds__(256) void reduce_batch_l2_kernel(BatchArgs a) {
   if (threadIdx.x < 64 && c < sg.width) sg.out[c] = sg.accumulate ? sg.out[c] + t : t;
 }
 
+// The same two levels with FOUR adjacent columns per lane (16-byte loads, 256 columns per workgroup): a quarter of the workgroups --
+// the scalar level 1 of a ViT-B layer is 4992 workgroups of ~4 KB each, 20 us of workgroup dispatch on the backward's critical
+// stream for 14 MB.  Per column the rows are summed in exactly the order of batch_colsum (wave w takes rows r0 + w, + 8, ... into s0 and
+// r0 + w + 4, ... into s1; four wave sums combined in order): results are bit-identical to the scalar kernels.
+__device__ __forceinline__ f32x4 batch_colsum4(const float* __restrict__ in, int64_t stride, int r0, int r1, int c, bool ok,
+                                               f32x4 (*red)[64]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) {
+      s0 += *reinterpret_cast<const f32x4*>(in + (int64_t)r * stride + c);
+      s1 += *reinterpret_cast<const f32x4*>(in + (int64_t)(r + 4) * stride + c);
+    }
+    if (r < r1) s0 += *reinterpret_cast<const f32x4*>(in + (int64_t)r * stride + c);
+  }
+  red[w][lane] = s0 + s1;
+  __syncthreads();
+  return ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+__global__ __launch_bounds__(256) void reduce_batch4_l1_kernel(BatchArgs a) {
+  __shared__ f32x4 red[4][64];
+  const int s = batch_find(a, blockIdx.x);
+  const XpReduceSeg sg = a.seg[s];
+  if (sg.nrows <= RB_DIRECT) return;
+  const int nsum = (sg.nrows + 31) / 32;
+  const int r0 = blockIdx.y * nsum;
+  if (r0 >= sg.nrows) return;
+  const int r1 = r0 + nsum < sg.nrows ? r0 + nsum : sg.nrows;
+  const int c = (blockIdx.x - a.cb0[s]) * 256 + (threadIdx.x & 63) * 4;
+  const f32x4 t = batch_colsum4(sg.in, sg.stride, r0, r1, c, c < sg.width, red);
+  if (threadIdx.x < 64 && c < sg.width) *reinterpret_cast<f32x4*>(a.part2[s] + (int64_t)blockIdx.y * sg.width + c) = t;
+}
+
+__global__ __launch_bounds__(256) void reduce_batch4_l2_kernel(BatchArgs a) {
+  __shared__ f32x4 red[4][64];
+  const int s = batch_find(a, blockIdx.x);
+  const XpReduceSeg sg = a.seg[s];
+  const bool direct = sg.nrows <= RB_DIRECT;
+  const int nsum = (sg.nrows + 31) / 32;
+  const int n2 = direct ? sg.nrows : (sg.nrows + nsum - 1) / nsum;
+  const int c = (blockIdx.x - a.cb0[s]) * 256 + (threadIdx.x & 63) * 4;
+  const f32x4 t = batch_colsum4(direct ? sg.in : a.part2[s], direct ? sg.stride : (int64_t)sg.width, 0, n2, c, c < sg.width, red);
+  if (threadIdx.x < 64 && c < sg.width) {
+    f32x4* o = reinterpret_cast<f32x4*>(sg.out + c);
+    *o = sg.accumulate ? *o + t : t;
+  }
+}
+
 }  // namespace
 
 // occupancy query for the default bf16 NT direct-to-LDS kernel: resident workgroups per CU at `lds_bytes` dynamic LDS
@@ -879,6 +929,14 @@ extern "C" int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, voi
   BatchArgs a;
   a.n = n;
   float* ws = (float*)workspace;
+  // four columns per lane when every segment allows 16-byte accesses (widths, pitches and addresses multiples of 4 floats: every
+  // segment the encoder layers pass); XPRETRAIN_DEBUG=rows_reduce_scalar keeps the one-column kernels (bit-identity test)
+  bool vec = ((uintptr_t)workspace & 15) == 0 && !xp_debug_flag("rows_reduce_scalar");
+  for (int i = 0; i < n && vec; ++i) {
+    const XpReduceSeg& sg = segs_host[i];
+    vec = sg.width % 4 == 0 && sg.stride % 4 == 0 && ((uintptr_t)sg.in & 15) == 0 && ((uintptr_t)sg.out & 15) == 0;
+  }
+  const int cw = vec ? 256 : 64;
   int cb = 0;
   bool any_l1 = false;
   for (int i = 0; i < n; ++i) {
@@ -886,16 +944,18 @@ extern "C" int xp_reduce_rows_batch(const XpReduceSeg* segs_host, int32_t n, voi
     XP_REQUIRE(sg.in && sg.out && sg.nrows > 0 && sg.width > 0 && sg.stride >= sg.width, "xp_reduce_rows_batch: bad segment %d", i);
     a.seg[i] = sg; a.part2[i] = ws; a.cb0[i] = cb;
     ws += (size_t)32 * sg.width;
-    cb += (int)cdiv(sg.width, 64);
+    cb += (int)cdiv(sg.width, cw);
     any_l1 = any_l1 || sg.nrows > RB_DIRECT;
   }
   for (int i = n; i <= XP_REDUCE_MAX_SEGS; ++i) a.cb0[i] = cb;
   hipStream_t st = (hipStream_t)stream;
   if (any_l1) {
-    reduce_batch_l1_kernel<<<dim3((unsigned)cb, 32), 256, 0, st>>>(a);
+    if (vec) reduce_batch4_l1_kernel<<<dim3((unsigned)cb, 32), 256, 0, st>>>(a);
+    else     reduce_batch_l1_kernel<<<dim3((unsigned)cb, 32), 256, 0, st>>>(a);
     XP_CHECK_LAUNCH("xp_reduce_rows_batch(level 1)");
   }
-  reduce_batch_l2_kernel<<<(unsigned)cb, 256, 0, st>>>(a);
+  if (vec) reduce_batch4_l2_kernel<<<(unsigned)cb, 256, 0, st>>>(a);
+  else     reduce_batch_l2_kernel<<<(unsigned)cb, 256, 0, st>>>(a);
   XP_CHECK_LAUNCH("xp_reduce_rows_batch(level 2)");
   return XP_OK;
 }
