@@ -627,8 +627,8 @@ def main():
             "vit_forward_train_mode_ms": round(vit_fwd_train_ms, 3),
             "vit_forward_frac_of_bf16_peak": round(f_vis * a.batch / (vit_fwd_train_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if vit_fwd_train_ms else 0.0,
             "vit_forward_ms": round(vit_fwd_ms, 3),
-            "vit_forward_note": "vit_forward_ms = inference mode (torch.no_grad: no pre-activation kept); the fraction of peak is "
-                                "quoted on vit_forward_train_mode_ms, the kernels the benchmark step runs",
+            "vit_forward_note": "vit_forward_ms = inference mode (torch.no_grad: no pre-activation kept; two half-batch chains like the training "
+                                "pass since round 6); the fraction of peak is quoted on vit_forward_train_mode_ms, the kernels the benchmark step runs",
             # dominant forward kernel; algorithmic bytes = A + W + two bf16 outputs
             "roofline": {"bound": "mfma", "kernel": f"gemm256_kernel<NT> (256x256 tiles, the kernel the training step runs) fc1 +bias+quick_gelu, two bf16 outputs [{k_rows}x768]x[768x3072]",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
