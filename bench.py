@@ -639,7 +639,7 @@ def main():
                          # rate of one of two concurrent chains, not of the chip; `one_chain` below is the per-kernel quantity of earlier rounds
                          "measured_in": "two-chain steps" if shipped else ("one-chain steps (XPRETRAIN_FWD_SPLIT=0)" if fc1_in_step_ms else "isolated launches"),
                          "workgroups": (k_rows + 255) // 256 * 12, "concurrent_chains": 2 if shipped else 1,
-                         "rocprof_check": "profiles/r06z_kernel_by_grid.txt: gemm256_kernel<false, false>, 444 workgroups (two-chain steps) / 888 (one-chain)",
+                         "rocprof_check": "profiles/r06zz_kernel_by_grid.txt: gemm256_kernel<false, false>, 444 workgroups (two-chain steps) / 888 (one-chain)",
                          "one_chain": {"kernel_ms": round(k1_ms, 4), "achieved": round(k1_tf, 1), "frac": round(k1_tf / PEAK_BF16_TFLOPS, 4),
                                        "measured_in": "one-chain steps (XPRETRAIN_FWD_SPLIT=0): the full-batch launch alone on the chip apart from the text tower" if fc1_in_step_ms else "isolated launches"},
                          "kernel_ms_isolated": round(k_ms_iso, 4), "frac_isolated": round(k_tf_iso / PEAK_BF16_TFLOPS, 4),
