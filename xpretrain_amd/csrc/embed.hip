@@ -84,8 +84,23 @@ __global__ __launch_bounds__(256) void vip_embed_bwd_pos_kernel(const T* __restr
   f32x4 s = {0, 0, 0, 0};
   float* out;
   if (blk < L) {
-    for (int64_t b = 0; b < B; ++b)
-      for (int t = 0; t < Tn; ++t) s += load4(dx + (b * S + M + (int64_t)t * L + blk) * D + d);
+    // B * Tn rows, summed in (b, t) order; eight loads in flight per lane (the additions keep their order: same bits as one by one)
+    const int64_t n = B * Tn;
+    int64_t q = 0;
+    for (; q + 8 <= n; q += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t b = (q + u) / Tn, t = (q + u) - b * Tn;
+        v[u] = load4(dx + (b * S + M + t * L + blk) * D + d);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; q < n; ++q) {
+      const int64_t b = q / Tn, t = q - b * Tn;
+      s += load4(dx + (b * S + M + t * L + blk) * D + d);
+    }
     out = d_pos + (int64_t)(1 + blk) * D + d;
   } else if (blk < L + M) {
     const int m = blk - L;
@@ -110,7 +125,15 @@ __global__ __launch_bounds__(256) void vip_embed_bwd_time_kernel(const T* __rest
   const int t = blockIdx.x % Tn;
   f32x4 s = {0, 0, 0, 0};
   const T* p = dx + (b * S + M + (int64_t)t * L) * D + d;
-  for (int l = 0; l < L; ++l) s += load4(p + (int64_t)l * D);
+  int l = 0;
+  for (; l + 8 <= L; l += 8) {           // eight loads in flight per lane; the additions keep their order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = load4(p + (int64_t)(l + u) * D);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; l < L; ++l) s += load4(p + (int64_t)l * D);
   store4(part + (int64_t)blockIdx.x * D + d, s);
 }
 

@@ -46,6 +46,40 @@ __global__ __launch_bounds__(256) XP_NO_PK_F32 void sgemm_strided_kernel(const f
     }
 }
 
+// Small similarity matrices (n <= 128: the local batch of one to a few GPUs): C[i][j] = alpha * <X[i,:], Y[j,:]> with ONE WAVE per
+// (i, j) -- 16-byte loads along d, 8 independent accumulator lanes per wave step, a fixed butterfly.  The 32x32-tile kernel above
+// runs a [8 x 512] x [512 x 8] problem as one workgroup walking 16 dependent k-steps of strided loads: 39 us of load latency on the
+// serial stretch between the forward and the backward (nothing else runs there); this one takes one load round trip.
+__global__ __launch_bounds__(256) XP_NO_PK_F32 void logits_small_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                        float* __restrict__ C, int n, int d,
+                                                                        const float* __restrict__ log_scale) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= n * n) return;
+  const int i = pair / n, j = pair - i * n;
+  const float* x = X + (int64_t)i * d;
+  const float* y = Y + (int64_t)j * d;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int k = lane * 4; k < d; k += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + k), b = *reinterpret_cast<const f32x4*>(y + k);
+    s0 += a[0] * b[0]; s1 += a[1] * b[1]; s2 += a[2] * b[2]; s3 += a[3] * b[3];
+  }
+  float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) C[(int64_t)i * n + j] = (log_scale ? expf(*log_scale) : 1.0f) * s;
+}
+
+// logits A[n][n] = e^ls V T^T: the small form up to n = 128 (d a multiple of 4, 16-byte aligned rows), the tiled form beyond
+static void launch_logits(const float* vis, const float* txt, float* A, int64_t n, int64_t d, const float* log_scale, hipStream_t st) {
+  if (n <= 128 && d % 4 == 0 && ((uintptr_t)vis & 15) == 0 && ((uintptr_t)txt & 15) == 0) {
+    logits_small_kernel<<<(unsigned)cdiv(n * n, 4), 256, 0, st>>>(vis, txt, A, (int)n, (int)d, log_scale);
+  } else {
+    dim3 gnn((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32));
+    sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, txt, 1, d, A, n, (int)n, (int)n, (int)d, log_scale);
+  }
+}
+
 // blocks 0..n-1: row i -> lse_r[i]; blocks n..2n-1: column j -> lse_c[j]   (one wave each)
 __global__ void lse_kernel(const float* __restrict__ A, float* __restrict__ lse_r, float* __restrict__ lse_c, int n) {
   const int lane = threadIdx.x;
@@ -238,10 +272,10 @@ extern "C" int xp_vsc_fc_loss(const float* vis, const float* txt, const float* i
   float* stats = G3 + n * n;
   float* part = stats + 6 * n;
   const int N = (int)n, D = (int)d;
-  dim3 gnn((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32)), gnd((unsigned)cdiv(d, 32), (unsigned)cdiv(n, 32));
-  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, txt, 1, d, S1, n, N, N, D, log_scale);
-  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, cap, 1, d, S2, n, N, N, D, log_scale);
-  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(img, d, 1, cap, 1, d, S3, n, N, N, D, log_scale);
+  dim3 gnd((unsigned)cdiv(d, 32), (unsigned)cdiv(n, 32));
+  launch_logits(vis, txt, S1, n, d, log_scale, st);
+  launch_logits(vis, cap, S2, n, d, log_scale, st);
+  launch_logits(img, cap, S3, n, d, log_scale, st);
   XP_CHECK_LAUNCH("xp_vsc_fc_loss(logits)");
   vsc_lse_kernel<<<(unsigned)(2 * n), 64, 0, st>>>(S1, S2, S3, stats, N);
   XP_CHECK_LAUNCH("xp_vsc_fc_loss(lse)");
@@ -278,9 +312,9 @@ extern "C" int xp_nce_loss(const float* vis, const float* txt, const float* log_
   float* lse_c = lse_r + n;
   float* part = lse_c + n;
   const int N = (int)n, D = (int)d;
-  dim3 gnn((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32)), gnd((unsigned)cdiv(d, 32), (unsigned)cdiv(n, 32));
+  dim3 gnd((unsigned)cdiv(d, 32), (unsigned)cdiv(n, 32));
   // A[i][j] = e^ls sum_k V[i][k] T[j][k]
-  sgemm_strided_kernel<<<gnn, 256, 0, st>>>(vis, d, 1, txt, 1, d, A, n, N, N, D, log_scale);
+  launch_logits(vis, txt, A, n, d, log_scale, st);
   XP_CHECK_LAUNCH("xp_nce_loss(logits)");
   lse_kernel<<<(unsigned)(2 * n), 64, 0, st>>>(A, lse_r, lse_c, N);
   XP_CHECK_LAUNCH("xp_nce_loss(lse)");
